@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI declared in include/sg_ops.h.
+
+The shared library is built in-tree by `python -m ga_gan_amd.build` (or
+`__graft_entry__.build()`).  There is no fallback: a missing or stale library is
+an ImportError, a failing call is a RuntimeError carrying `sg_last_error()`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsgops.so')
+
+SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
+           'sg_mbstd_forward', 'sg_mbstd_backward')
+
+DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
+
+i32, i64, f32, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class Upfirdn2dParams(ctypes.Structure):
+    _fields_ = [('x', vp), ('f', vp), ('y', vp), ('dtype', i32),
+                ('up_x', i32), ('up_y', i32), ('down_x', i32), ('down_y', i32),
+                ('pad_x0', i32), ('pad_y0', i32), ('flip', i32), ('gain', f32),
+                ('in_w', i32), ('in_h', i32), ('in_c', i32), ('in_n', i32),
+                ('in_stride_w', i64), ('in_stride_h', i64), ('in_stride_c', i64), ('in_stride_n', i64),
+                ('f_w', i32), ('f_h', i32), ('f_stride_w', i64), ('f_stride_h', i64),
+                ('out_w', i32), ('out_h', i32),
+                ('out_stride_w', i64), ('out_stride_h', i64), ('out_stride_c', i64), ('out_stride_n', i64)]
+
+
+class BiasActParams(ctypes.Structure):
+    _fields_ = [('x', vp), ('b', vp), ('xref', vp), ('yref', vp), ('dy', vp), ('y', vp),
+                ('dtype', i32), ('grad', i32), ('act', i32),
+                ('alpha', f32), ('gain', f32), ('clamp', f32),
+                ('size_x', i64), ('size_b', i32), ('step_b', i64)]
+
+
+class MbstdParams(ctypes.Structure):
+    _fields_ = [('x', vp), ('dy', vp), ('out', vp), ('dtype', i32),
+                ('n', i32), ('c', i32), ('hw', i32), ('g', i32), ('f', i32)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loaded once per process)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(f'{LIB_PATH} is missing: build the HIP library first (python -m ga_gan_amd.build)')
+        handle = ctypes.CDLL(LIB_PATH)
+        missing = [s for s in SYMBOLS if not hasattr(handle, s)]
+        if missing:
+            raise ImportError(f'{LIB_PATH} does not export {missing}: rebuild it')
+        handle.sg_last_error.restype = ctypes.c_char_p
+        handle.sg_version.restype = ctypes.c_int
+        handle.sg_upfirdn2d_out_size.argtypes = [ctypes.c_int] * 6
+        for name, struct in (('sg_upfirdn2d', Upfirdn2dParams), ('sg_bias_act', BiasActParams),
+                             ('sg_mbstd_forward', MbstdParams), ('sg_mbstd_backward', MbstdParams)):
+            fn = getattr(handle, name)
+            fn.argtypes = [ctypes.POINTER(struct), vp]
+            fn.restype = ctypes.c_int
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed ({rc}): {lib().sg_last_error().decode()}')
+
+
+def dtype_code(t):
+    try:
+        return DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f'unsupported dtype {t.dtype}') from None
+
+
+def stream_of(t):
+    """The HIP stream torch is currently enqueueing on for t's device."""
+    return vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return vp(t.data_ptr()) if t is not None and t.numel() > 0 else vp(None)

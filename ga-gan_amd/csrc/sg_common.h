@@ -1,0 +1,79 @@
+// Shared helpers for the gfx950 kernels: storage <-> compute type traits, 16-byte
+// vector access, error reporting across the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "sg_ops.h"
+
+namespace sg {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- error text, one slot per host thread ---------------------------------
+char* error_slot();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define SG_REQUIRE(cond, code, ...)                      \
+    do {                                                 \
+        if (!(cond)) return ::sg::fail((code), __VA_ARGS__); \
+    } while (0)
+
+// ---- element types ----------------------------------------------------------
+// Storage type T -> arithmetic type acc_t (float for f32/f16/bf16, double for f64).
+template <class T> struct Elem;
+template <> struct Elem<float> {
+    using acc_t = float;
+    static __device__ __forceinline__ float load(float v) { return v; }
+    static __device__ __forceinline__ float store(float v) { return v; }
+};
+template <> struct Elem<double> {
+    using acc_t = double;
+    static __device__ __forceinline__ double load(double v) { return v; }
+    static __device__ __forceinline__ double store(double v) { return v; }
+};
+template <> struct Elem<__half> {
+    using acc_t = float;
+    static __device__ __forceinline__ float load(__half v) { return __half2float(v); }
+    static __device__ __forceinline__ __half store(float v) { return __float2half(v); }
+};
+template <> struct Elem<__hip_bfloat16> {
+    using acc_t = float;
+    static __device__ __forceinline__ float load(__hip_bfloat16 v) { return __bfloat162float(v); }
+    static __device__ __forceinline__ __hip_bfloat16 store(float v) { return __float2bfloat16(v); }
+};
+
+// A 16-byte packet of T, moved with one dwordx4 access.
+template <class T> struct alignas(16) Pack {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
+template <class T> __device__ __forceinline__ Pack<T> load_pack(const T* p) {
+    return *reinterpret_cast<const Pack<T>*>(p);
+}
+template <class T> __device__ __forceinline__ void store_pack(T* p, const Pack<T>& v) {
+    *reinterpret_cast<Pack<T>*>(p) = v;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Dispatch a callable templated on the storage type.
+#define SG_DISPATCH_DTYPE(dtype, ALLOW_F64, ...)                                   \
+    switch (dtype) {                                                               \
+        case SG_F32: { using T = float; __VA_ARGS__; break; }                      \
+        case SG_F16: { using T = __half; __VA_ARGS__; break; }                     \
+        case SG_BF16: { using T = __hip_bfloat16; __VA_ARGS__; break; }            \
+        case SG_F64:                                                               \
+            if (ALLOW_F64) { using T = double; __VA_ARGS__; break; }               \
+            return ::sg::fail(SG_ERR_UNSUPPORTED, "float64 is not supported here"); \
+        default: return ::sg::fail(SG_ERR_INVALID_ARGUMENT, "unknown dtype %d", (int)(dtype)); \
+    }
+
+}  // namespace sg

@@ -1,0 +1,227 @@
+// upfirdn2d: zero-stuff, pad / crop, FIR-filter and decimate every (sample, channel)
+// plane.  Bandwidth-bound: the ideal traffic is one read of x and one write of y.
+//
+// Two kernels:
+//   * tiled   - rows contiguous in memory (stride_w == 1), filter at most 4x4 taps,
+//               up/down in {1,2}: one workgroup of 256 lanes produces a TILE_W x TILE_H
+//               output tile of one plane.  The input footprint of the tile (with its
+//               filter halo) is staged once through LDS with row-contiguous loads, the
+//               (flipped) taps sit in LDS too, and every lane then reads only LDS.
+//   * generic - any strides (channels-last, slices), any filter size, any integer
+//               up/down factors; one lane per output element, taps walked in global
+//               memory.
+// Tap indexing follows the reference kernels (torch_utils/ops/upfirdn2d.cu:42-89 and
+// :141-195): for output o, mid = o * down + up - 1 - pad0, first input sample
+// floor(mid / up), first tap (in + 1) * up - mid - 1 of the flipped filter, then every
+// up-th tap.
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+__device__ __forceinline__ int floor_div(int a, int b) {
+    int q = a / b;
+    return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+// ---------------------------------------------------------------------------
+// Generic kernel.
+template <class T>
+__global__ void __launch_bounds__(256) upfirdn2d_generic_kernel(sg_upfirdn2d_params p, int64_t total) {
+    using S = typename Elem<T>::acc_t;
+    const T* __restrict__ x = (const T*)p.x;
+    T* __restrict__ y = (T*)p.y;
+    const bool channels_fastest = (p.in_stride_c == 1 && p.in_c > 1);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        // Walk the output in the order its memory is laid out, so that stores coalesce.
+        int64_t r = idx;
+        int c, ox;
+        if (channels_fastest) {
+            c = (int)(r % p.in_c); r /= p.in_c;
+            ox = (int)(r % p.out_w); r /= p.out_w;
+        } else {
+            ox = (int)(r % p.out_w); r /= p.out_w;
+        }
+        const int oy = (int)(r % p.out_h); r /= p.out_h;
+        if (!channels_fastest) { c = (int)(r % p.in_c); r /= p.in_c; }
+        const int n = (int)r;
+
+        const int mid_x = ox * p.down_x + p.up_x - 1 - p.pad_x0;
+        const int mid_y = oy * p.down_y + p.up_y - 1 - p.pad_y0;
+        const int in_x0 = min(max(floor_div(mid_x, p.up_x), 0), p.in_w);
+        const int in_y0 = min(max(floor_div(mid_y, p.up_y), 0), p.in_h);
+        const int w = min(max(floor_div(mid_x + p.f_w, p.up_x), 0), p.in_w) - in_x0;
+        const int h = min(max(floor_div(mid_y + p.f_h, p.up_y), 0), p.in_h) - in_y0;
+        int tap_x0 = mid_x + p.f_w - (in_x0 + 1) * p.up_x;
+        int tap_y0 = mid_y + p.f_h - (in_y0 + 1) * p.up_y;
+        int step_x = -p.up_x, step_y = -p.up_y;
+        if (p.flip) {
+            tap_x0 = p.f_w - 1 - tap_x0;
+            tap_y0 = p.f_h - 1 - tap_y0;
+            step_x = p.up_x;
+            step_y = p.up_y;
+        }
+        const T* xp = x + (int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c;
+        S acc = (S)0;
+        for (int j = 0; j < h; j++) {
+            const T* row = xp + (int64_t)(in_y0 + j) * p.in_stride_h + (int64_t)in_x0 * p.in_stride_w;
+            const float* frow = p.f + (int64_t)(tap_y0 + j * step_y) * p.f_stride_h;
+            for (int i = 0; i < w; i++)
+                acc += Elem<T>::load(row[(int64_t)i * p.in_stride_w]) * (S)frow[(int64_t)(tap_x0 + i * step_x) * p.f_stride_w];
+        }
+        acc *= (S)p.gain;
+        y[(int64_t)n * p.out_stride_n + (int64_t)c * p.out_stride_c + (int64_t)oy * p.out_stride_h +
+          (int64_t)ox * p.out_stride_w] = Elem<T>::store(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Tiled kernel.  FW / FH are the tap counts the code is unrolled for (the actual
+// filter may be smaller; missing taps are zero) and must be multiples of UPX / UPY.
+template <class T, int UPX, int UPY, int DOWNX, int DOWNY, int FW, int FH, int TILE_W, int TILE_H>
+__global__ void __launch_bounds__(256) upfirdn2d_tiled_kernel(sg_upfirdn2d_params p, int tiles_x, int tiles_y) {
+    using S = float;
+    constexpr int IN_W = ((TILE_W - 1) * DOWNX + FW - 1) / UPX + 1;
+    constexpr int IN_H = ((TILE_H - 1) * DOWNY + FH - 1) / UPY + 1;
+    constexpr int IN_PITCH = IN_W | 1;  // odd pitch: rows start on different banks
+    __shared__ S s_f[FH][FW];
+    __shared__ S s_x[IN_H * IN_PITCH];
+
+    const T* __restrict__ x = (const T*)p.x;
+    T* __restrict__ y = (T*)p.y;
+    const int tid = threadIdx.x;
+
+    // Taps, flipped the way the correlation below consumes them.
+    for (int t = tid; t < FW * FH; t += 256) {
+        const int fy = t / FW, fx = t % FW;
+        S v = 0;
+        if (fx < p.f_w && fy < p.f_h) {
+            const int sx = p.flip ? fx : p.f_w - 1 - fx;
+            const int sy = p.flip ? fy : p.f_h - 1 - fy;
+            v = p.f[(int64_t)sx * p.f_stride_w + (int64_t)sy * p.f_stride_h];
+        }
+        s_f[fy][fx] = v;
+    }
+
+    // blockIdx.x enumerates (tile_x, tile_y); blockIdx.y strides over the n*c planes.
+    const int tile_x = blockIdx.x % tiles_x;
+    const int tile_y = blockIdx.x / tiles_x;
+    const int out_x0 = tile_x * TILE_W;
+    const int out_y0 = tile_y * TILE_H;
+    const int mid_x0 = out_x0 * DOWNX + UPX - 1 - p.pad_x0;
+    const int mid_y0 = out_y0 * DOWNY + UPY - 1 - p.pad_y0;
+    const int in_x0 = floor_div(mid_x0, UPX);
+    const int in_y0 = floor_div(mid_y0, UPY);
+    const int planes = p.in_n * p.in_c;
+
+    for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+        const int n = plane / p.in_c;
+        const int c = plane - n * p.in_c;
+        const T* xp = x + (int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c;
+        T* yp = y + (int64_t)n * p.out_stride_n + (int64_t)c * p.out_stride_c;
+
+        __syncthreads();  // previous plane's readers are done with s_x (and s_f is written)
+        for (int t = tid; t < IN_H * IN_W; t += 256) {
+            const int ry = t / IN_W, rx = t - ry * IN_W;
+            const int ix = in_x0 + rx, iy = in_y0 + ry;
+            S v = 0;
+            if (ix >= 0 && iy >= 0 && ix < p.in_w && iy < p.in_h) v = Elem<T>::load(xp[(int64_t)iy * p.in_stride_h + ix]);
+            s_x[ry * IN_PITCH + rx] = v;
+        }
+        __syncthreads();
+
+        for (int t = tid; t < TILE_W * TILE_H; t += 256) {
+            const int ry = t / TILE_W, rx = t - ry * TILE_W;
+            const int ox = out_x0 + rx, oy = out_y0 + ry;
+            const int mid_x = mid_x0 + rx * DOWNX;
+            const int mid_y = mid_y0 + ry * DOWNY;
+            const int ix = floor_div(mid_x, UPX);
+            const int iy = floor_div(mid_y, UPY);
+            const int tap_x = (ix + 1) * UPX - mid_x - 1;
+            const int tap_y = (iy + 1) * UPY - mid_y - 1;
+            const S* sx = s_x + (iy - in_y0) * IN_PITCH + (ix - in_x0);
+            S acc = 0;
+#pragma unroll
+            for (int j = 0; j < FH / UPY; j++)
+#pragma unroll
+                for (int i = 0; i < FW / UPX; i++) acc += sx[j * IN_PITCH + i] * s_f[tap_y + j * UPY][tap_x + i * UPX];
+            if (ox < p.out_w && oy < p.out_h) yp[(int64_t)oy * p.out_stride_h + ox] = Elem<T>::store(acc * p.gain);
+        }
+    }
+}
+
+template <class T, int UPX, int UPY, int DOWNX, int DOWNY, int FW, int FH, int TILE_W, int TILE_H>
+int launch_tiled(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    const int tiles_x = (p.out_w + TILE_W - 1) / TILE_W;
+    const int tiles_y = (p.out_h + TILE_H - 1) / TILE_H;
+    const int64_t planes = (int64_t)p.in_n * p.in_c;
+    const int64_t tiles = (int64_t)tiles_x * tiles_y;
+    SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
+    // Enough workgroups for every CU (256 CUs x 8), the remaining planes are looped over.
+    int64_t gy = planes;
+    const int64_t want = 4096;
+    if (tiles * gy > want) gy = (want + tiles - 1) / tiles;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UPX, UPY, DOWNX, DOWNY, FW, FH, TILE_W, TILE_H>),
+                       dim3((unsigned)tiles, (unsigned)gy), dim3(256), 0, stream, p, tiles_x, tiles_y);
+    return check_launch("sg_upfirdn2d (tiled)");
+}
+
+template <class T>
+int launch_generic(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    const int64_t total = (int64_t)p.out_w * p.out_h * p.in_c * p.in_n;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL((upfirdn2d_generic_kernel<T>), dim3((unsigned)grid), dim3(256), 0, stream, p, total);
+    return check_launch("sg_upfirdn2d (generic)");
+}
+
+template <class T>
+int launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    const bool rows_contiguous = p.in_stride_w == 1 && p.out_stride_w == 1;
+    if (rows_contiguous && sizeof(T) <= 4 && p.f_w <= 4 && p.f_h <= 4) {
+        const int ux = p.up_x, uy = p.up_y, dx = p.down_x, dy = p.down_y;
+        if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return launch_tiled<T, 1, 1, 1, 1, 4, 4, 64, 16>(p, stream);
+        if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return launch_tiled<T, 2, 2, 1, 1, 4, 4, 64, 16>(p, stream);
+        if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return launch_tiled<T, 1, 1, 2, 2, 4, 4, 64, 8>(p, stream);
+    }
+    return launch_generic<T>(p, stream);
+}
+
+template <>
+int launch<double>(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    return launch_generic<double>(p, stream);
+}
+
+}  // namespace
+}  // namespace sg
+
+extern "C" int sg_upfirdn2d_out_size(int in_size, int up, int pad0, int pad1, int f_size, int down) {
+    if (up < 1 || down < 1 || f_size < 1) return -1;
+    const int64_t v = (int64_t)in_size * up + pad0 + pad1 - f_size + down;
+    if (v < 0) return 0;  // C division truncates toward zero; a negative numerator means "no output"
+    return (int)(v / down);
+}
+
+extern "C" int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream) {
+    using namespace sg;
+    SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
+    SG_REQUIRE(p->up_x >= 1 && p->up_y >= 1, SG_ERR_INVALID_ARGUMENT, "upsampling factor must be at least 1");
+    SG_REQUIRE(p->down_x >= 1 && p->down_y >= 1, SG_ERR_INVALID_ARGUMENT, "downsampling factor must be at least 1");
+    SG_REQUIRE(p->f_w >= 1 && p->f_h >= 1, SG_ERR_INVALID_ARGUMENT, "f must be at least 1x1");
+    SG_REQUIRE(p->in_w >= 0 && p->in_h >= 0 && p->in_c >= 0 && p->in_n >= 0, SG_ERR_INVALID_ARGUMENT,
+               "negative input size");
+    SG_REQUIRE(p->out_w >= 1 && p->out_h >= 1, SG_ERR_INVALID_ARGUMENT, "output must be at least 1x1");
+    SG_REQUIRE((int64_t)p->in_w * p->in_h * p->in_c * p->in_n <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "x is too large");
+    SG_REQUIRE((int64_t)p->out_w * p->out_h * p->in_c * p->in_n <= INT32_MAX, SG_ERR_INVALID_ARGUMENT,
+               "output is too large");
+    // The caller's output must not be larger than the filter footprint allows (else reads run past x's padding
+    // logic into other planes); out_w * down <= in_w * up + pad0 + pad1 - f_w + down cannot be checked without
+    // pad1, so bound it by the widest legal choice pad1 -> the kernels clamp every read to [0, in) anyway.
+    if (p->in_c == 0 || p->in_n == 0) return SG_OK;
+    SG_REQUIRE(p->x && p->f && p->y, SG_ERR_NULL_POINTER, "x, f and y must not be NULL");
+    SG_DISPATCH_DTYPE(p->dtype, true, return launch<T>(*p, (hipStream_t)stream));
+    return SG_OK;
+}

@@ -1,0 +1,132 @@
+/*
+ * sg_ops.h - C ABI of the MI355X (gfx950) kernels for the StyleGAN2 few-shot
+ * training hot path.  Plain pointers and sizes only; every pointer is a device
+ * pointer unless stated otherwise; every entry point enqueues on the HIP stream
+ * it is given (NULL = the default stream), allocates nothing, keeps no state
+ * between calls and may be called concurrently from several host threads.
+ *
+ * Return value: 0 on success, a negative sg_status on a rejected argument
+ * (nothing was launched), or a positive hipError_t from the launch.  The text
+ * for the calling thread's last failure is returned by sg_last_error().
+ *
+ * Citations name the interface of the reference (ndhlt/GA-GAN,
+ * DissimilarDomains/) that each entry point stands in for.
+ */
+#ifndef SG_OPS_H
+#define SG_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sg_stream_t; /* a hipStream_t */
+
+enum sg_dtype { SG_F32 = 0, SG_F16 = 1, SG_BF16 = 2, SG_F64 = 3 };
+
+enum sg_status {
+    SG_OK = 0,
+    SG_ERR_INVALID_ARGUMENT = -1, /* shape / size / enum out of range */
+    SG_ERR_UNSUPPORTED = -2,      /* valid but not implemented for this dtype / layout */
+    SG_ERR_NULL_POINTER = -3
+};
+
+/* Library version (major * 1000 + minor). */
+int sg_version(void);
+
+/* Message for the last non-zero return on the calling thread ("" if none). */
+const char* sg_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * upfirdn2d: per (sample, channel) plane  zero-stuff by `up`, pad (negative =
+ * crop), correlate with the flipped FIR filter (not flipped when `flip` != 0),
+ * keep every `down`-th sample, scale by `gain`.  Accumulation is float
+ * (double for SG_F64).
+ *
+ * Replaces the native entry point `upfirdn2d(x, f, upx, upy, downx, downy,
+ * padx0, padx1, pady0, pady1, flip, gain)` of
+ * torch_utils/ops/upfirdn2d.cpp:16-94 and its parameter block
+ * torch_utils/ops/upfirdn2d.h:14-40.  Strides are in elements, so
+ * channels-last and sliced tensors are accepted; the filter is float32
+ * [f_h, f_w] with its own strides.  The caller allocates y with
+ *   out_w = (in_w * up_x + pad_x0 + pad_x1 - f_w + down_x) / down_x
+ * (same for h), which sg_upfirdn2d_out_size() computes.
+ */
+typedef struct sg_upfirdn2d_params {
+    const void* x;
+    const float* f;
+    void* y;
+    int32_t dtype; /* sg_dtype of x and y */
+    int32_t up_x, up_y, down_x, down_y;
+    int32_t pad_x0, pad_y0;
+    int32_t flip;
+    float gain;
+    int32_t in_w, in_h, in_c, in_n;
+    int64_t in_stride_w, in_stride_h, in_stride_c, in_stride_n;
+    int32_t f_w, f_h;
+    int64_t f_stride_w, f_stride_h;
+    int32_t out_w, out_h;
+    int64_t out_stride_w, out_stride_h, out_stride_c, out_stride_n;
+} sg_upfirdn2d_params;
+
+int sg_upfirdn2d_out_size(int in_size, int up, int pad0, int pad1, int f_size, int down);
+int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * bias_act:  y = clamp(act(x + b[(i / step_b) % size_b]) * gain)  for grad = 0,
+ * the first-order backward through the saved output `yref` (or input `xref`
+ * for swish) for grad = 1, the second-order term for grad = 2.  x, xref, yref,
+ * dy and y are dense arrays of size_x elements with one common layout; b,
+ * xref, yref and dy may be NULL ("absent").  act = 1..9 (linear, relu, lrelu,
+ * tanh, sigmoid, elu, selu, softplus, swish); clamp < 0 disables clamping.
+ *
+ * Replaces the native entry point `bias_act(x, b, xref, yref, dy, grad, dim,
+ * act, alpha, gain, clamp)` of torch_utils/ops/bias_act.cpp:32-90 and its
+ * parameter block torch_utils/ops/bias_act.h:12-31 (`dim` is folded into
+ * step_b = stride of that dimension, as bias_act.cpp:73 does).
+ */
+typedef struct sg_bias_act_params {
+    const void* x;
+    const void* b;
+    const void* xref;
+    const void* yref;
+    const void* dy;
+    void* y;
+    int32_t dtype;
+    int32_t grad;
+    int32_t act;
+    float alpha, gain, clamp;
+    int64_t size_x;
+    int32_t size_b;
+    int64_t step_b;
+} sg_bias_act_params;
+
+int sg_bias_act(const sg_bias_act_params* p, sg_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Minibatch standard deviation (training/networks.py:1284-1301, a composite of
+ * seven tensor ops in the reference; no native counterpart there).
+ * x is dense [n, c, h, w]; y is dense [n, c + f, h, w].  The batch is split
+ * into n / g groups of g samples (sample i belongs to group i % (n / g)) and
+ * the channels into f sets of c / f; channel c + j of every sample of a group
+ * holds mean over (set j, h, w) of sqrt(var over the group + 1e-8).
+ * Forward copies x into y[:, :c] as well.  Backward takes dy [n, c + f, h, w]
+ * and writes dx [n, c, h, w] = dy[:, :c] + d(stat)/dx contribution.
+ */
+typedef struct sg_mbstd_params {
+    const void* x;  /* [n, c, h, w] */
+    const void* dy; /* backward only: [n, c + f, h, w] */
+    void* out;      /* forward: y [n, c + f, h, w]; backward: dx [n, c, h, w] */
+    int32_t dtype;
+    int32_t n, c, hw; /* hw = h * w */
+    int32_t g, f;
+} sg_mbstd_params;
+
+int sg_mbstd_forward(const sg_mbstd_params* p, sg_stream_t stream);
+int sg_mbstd_backward(const sg_mbstd_params* p, sg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SG_OPS_H */
