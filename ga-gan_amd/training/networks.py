@@ -1,0 +1,770 @@
+"""StyleGAN2 generator / discriminator with the StyleDomain few-shot parameterisations
+(Affine+, AffineLight+, StyleSpace offsets), running on the gfx950 op API.
+
+Drop-in for the reference's `training/networks.py`: same class names, constructor
+arguments, forward arguments and `state_dict()` names / shapes, so a checkpoint of
+the reference loads with `load_state_dict(strict=True)`.  Differences, all
+deliberate:
+  * blocks flagged `use_fp16` run in `LOW_PRECISION_DTYPE` (bfloat16 by default on
+    MI355X; float16 is still accepted and then gets the reference's overflow
+    pre-normalisation, training/networks.py:621-627);
+  * the demodulation coefficients are computed as rsqrt(s^2 @ sum_k(W^2)^T + eps)
+    instead of materialising the per-sample weight tensor [N, O, I, k, k]
+    (training/networks.py:633-636) - same value, 1/(9 N)-th of the memory traffic;
+  * `SynthesisBlock.forward` up-samples the image skip only when one exists (the
+    fork's lines 1057-1063 crash on the first block; this is the upstream wiring);
+  * `MinibatchStdLayer` is one kernel.
+There is no CPU path: every op refuses CPU tensors.
+"""
+import math
+import re
+
+import numpy as np
+import torch
+
+from ..torch_utils import misc
+from ..torch_utils.ops import bias_act
+from ..torch_utils.ops import conv2d_resample
+from ..torch_utils.ops import fma
+from ..torch_utils.ops import minibatch_std
+from ..torch_utils.ops import upfirdn2d
+
+# dtype of the blocks the reference runs in float16 (`use_fp16`).
+LOW_PRECISION_DTYPE = torch.bfloat16
+
+
+def set_low_precision_dtype(dtype):
+    global LOW_PRECISION_DTYPE
+    assert dtype in (torch.bfloat16, torch.float16, torch.float32)
+    LOW_PRECISION_DTYPE = dtype
+
+
+# ----------------------------------------------------------------------------
+# Domain-modulation parameterisations (reference: training/networks.py:24-53, 87-137).
+
+_RANKS = [1, 5, 10, 20, 50, 100, 256, 512]
+_BASE = ['in', 'out', 'spatial', 'in_spatial', 'out_spatial', 'out_in']
+out_in_base_parametrizations = _BASE + [b + '_additive' for b in _BASE]
+_DECOMP = (['out+in'] + [f'out_in_{k}' for k in _RANKS] + [f'out_in_{k}_dual' for k in _RANKS]
+           + [f'out_in_{k}_{t}{suffix}' for suffix in ('', '_train_in', '_train_out')
+              for k in _RANKS for t in range(1, 512 // k + 1)])
+out_in_decomposition_parametrizations = _DECOMP + [d + '_additive' for d in _DECOMP]
+_AFFINE = [f'affine_out_in_{k}_{t}' for k in _RANKS for t in range(1, 512 // k + 1)]
+affine_out_in_decomposition_parametrizations = _AFFINE + [a + '_additive' for a in _AFFINE]
+
+_WEIGHT_KINDS = set(out_in_base_parametrizations) | set(out_in_decomposition_parametrizations)
+_AFFINE_KINDS = set(affine_out_in_decomposition_parametrizations)
+_STYLE_KINDS = ('multiplicative', 'additive', 'multiplicative_w_space', 'additive_w_space')
+_DECOMP_RE = re.compile(r'^(?:affine_)?out_in_([0-9]+)(?:_(dual|[0-9]+))?(?:_(train_in|train_out))?(?:_additive)?$')
+
+
+def split_parameterization(use_domain_modulation, domain_modulation_parametrization):
+    """'a,b,c' -> (S/W-space kind, conv-weight kind, affine-weight kind); at most one of each."""
+    if not use_domain_modulation:
+        return None, None, None
+    names = domain_modulation_parametrization.split(',')
+    groups = ([n for n in names if n not in _WEIGHT_KINDS and n not in _AFFINE_KINDS],
+              [n for n in names if n in _WEIGHT_KINDS],
+              [n for n in names if n in _AFFINE_KINDS])
+    for g in groups:
+        if len(g) > 1:
+            raise ValueError(f'Too many types of domain modulation: {g}')
+    return tuple(g[0] if g else None for g in groups)
+
+
+def _unit_rows(t):
+    if torch.linalg.norm(t).item() > 1e-6:
+        t /= torch.linalg.norm(t, dim=1, keepdim=True)
+
+
+def _unit_cols(t):
+    if torch.linalg.norm(t).item() > 1e-6:
+        t /= torch.linalg.norm(t, dim=0, keepdim=True)
+
+
+def _register_low_rank_terms(module, kind, out_dim, in_dim):
+    """Low-rank offset terms  sum_t out_t[O, K] @ in_t[K, I].  Which factor is trained
+    (Parameter) and which is a fixed random projection (buffer) depends on the kind
+    (reference: training/networks.py:233-410 and 163-216)."""
+    ins, outs = [], []
+    if kind.startswith('out+in'):
+        module.register_parameter('weights_offset_in_0', torch.nn.Parameter(torch.zeros(1, in_dim)))
+        module.register_parameter('weights_offset_out_0', torch.nn.Parameter(torch.zeros(out_dim, 1)))
+        ins, outs = ['weights_offset_in_0'], ['weights_offset_out_0']
+    else:
+        m = _DECOMP_RE.match(kind)
+        if m is None:
+            raise ValueError(f'Unknown type of domain modulation: {kind}')
+        rank, second, train = int(m.group(1)), m.group(2), m.group(3)
+
+        def param(name, tensor):
+            module.register_parameter(name, torch.nn.Parameter(tensor))
+
+        def buf(name, tensor):
+            module.register_buffer(name, tensor)
+
+        if second == 'dual':   # A1 @ B1 + A2 @ B2 with B1 and A2 fixed
+            buf('weights_offset_in_0', torch.randn(rank, in_dim))
+            param('weights_offset_in_1', torch.zeros(rank, in_dim))
+            param('weights_offset_out_0', torch.zeros(out_dim, rank))
+            buf('weights_offset_out_1', torch.randn(out_dim, rank))
+            ins, outs = ['weights_offset_in_0', 'weights_offset_in_1'], ['weights_offset_out_0', 'weights_offset_out_1']
+        else:
+            terms = int(second) if second is not None else 1
+            for t in range(terms):
+                if second is None:                      # single term, both factors trained from zero
+                    param(f'weights_offset_in_{t}', torch.zeros(rank, in_dim))
+                    param(f'weights_offset_out_{t}', torch.zeros(out_dim, rank))
+                elif train is None:                     # both trained, `in` starts random
+                    param(f'weights_offset_in_{t}', torch.randn(rank, in_dim))
+                    param(f'weights_offset_out_{t}', torch.zeros(out_dim, rank))
+                elif train == 'train_in':
+                    param(f'weights_offset_in_{t}', torch.zeros(rank, in_dim))
+                    buf(f'weights_offset_out_{t}', torch.randn(out_dim, rank))
+                else:                                   # train_out
+                    buf(f'weights_offset_in_{t}', torch.randn(rank, in_dim))
+                    param(f'weights_offset_out_{t}', torch.zeros(out_dim, rank))
+                ins.append(f'weights_offset_in_{t}')
+                outs.append(f'weights_offset_out_{t}')
+    with torch.no_grad():
+        for name in ins:
+            _unit_rows(getattr(module, name).data)
+        for name in outs:
+            _unit_cols(getattr(module, name).data)
+    module.weights_offset_in, module.weights_offset_out = ins, outs
+
+
+def register_affine_weights_domain_modulation(self):
+    kind = self.affine_weights_domain_modulation_parametrization
+    if kind not in _AFFINE_KINDS:
+        raise ValueError(f'Unknown type of domain modulation: {kind}')
+    out_features, in_features = self.weight.shape
+    _register_low_rank_terms(self, kind, out_features, in_features)
+    self.register_buffer('ones_weights', self.weight.new_ones(out_features, in_features))
+
+
+def register_weights_domain_modulation(self):
+    kind = self.weights_domain_modulation_parametrization
+    out_channels, in_channels, k0, k1 = self.weight.shape
+    base = kind[:-len('_additive')] if kind.endswith('_additive') else kind
+    base_shapes = {'in': (1, in_channels, 1, 1), 'out': (out_channels, 1, 1, 1), 'spatial': (1, 1, k0, k1),
+                   'in_spatial': (1, in_channels, k0, k1), 'out_spatial': (out_channels, 1, k0, k1),
+                   'out_in': (out_channels, in_channels, 1, 1)}
+    if base in base_shapes:
+        self.weights_offset = torch.nn.Parameter(torch.zeros(*base_shapes[base]))
+        self.register_buffer('ones_weights', torch.ones_like(self.weights_offset))
+    elif kind in out_in_decomposition_parametrizations:
+        _register_low_rank_terms(self, kind, out_channels, in_channels)
+        self.register_buffer('ones_weights', self.weight.new_ones(out_channels, in_channels, 1, 1))
+    else:
+        raise ValueError(f'Unknown type of domain modulation: {kind}')
+
+
+def register_domain_modulation(self, in_channels, w_dim):
+    kind = self.domain_modulation_parametrization
+    if kind not in _STYLE_KINDS:
+        raise ValueError(f'Unknown type of domain modulation: {kind}')
+    dim = w_dim if kind.endswith('w_space') else in_channels
+    if kind.startswith('multiplicative'):
+        self.register_buffer('ones', torch.ones((1, dim)))
+    self.offset = torch.nn.Parameter(torch.zeros(1, dim))
+    self.register_buffer('offset_mask', torch.ones_like(self.offset))
+
+
+def register_modulation(self, in_channels, w_dim, use_domain_modulation, domain_modulation_parametrization,
+                        generator_requires_grad_parts):
+    """Create the offset parameters a layer needs for the chosen parameterisation.  Conv-weight
+    offsets exist only on layers that `generator_requires_grad_parts` selects
+    ('all', '<synt|tRGB>_weights_offset' or '<...>_weights_offset.b<res>')."""
+    self.use_domain_modulation = use_domain_modulation
+    (self.domain_modulation_parametrization, self.weights_domain_modulation_parametrization,
+     self.affine.affine_weights_domain_modulation_parametrization) = split_parameterization(
+        use_domain_modulation, domain_modulation_parametrization)
+    if self.domain_modulation_parametrization is not None:
+        register_domain_modulation(self, in_channels, w_dim)
+    group = 'tRGB_weights_offset' if self.is_rgb else 'synt_weights_offset'
+    selected = any(p in generator_requires_grad_parts for p in ('all', group, f'{group}.b{self.resolution:d}'))
+    if selected and self.weights_domain_modulation_parametrization is not None:
+        register_weights_domain_modulation(self)
+    else:
+        self.weights_domain_modulation_parametrization = None
+    if self.affine.affine_weights_domain_modulation_parametrization is not None:
+        register_affine_weights_domain_modulation(self.affine)
+
+
+def get_style_space_modifications(layer_idx, styles, style_space_modifications):
+    """Per-layer edit vector and direction mask from ((layer, channel), magnitude, factor) triples."""
+    if style_space_modifications is None:
+        return None, None
+    shape = [1] * styles.ndim
+    shape[1] = styles.shape[1]
+    modifications = torch.zeros(shape, device=styles.device, dtype=styles.dtype)
+    offset_factors = torch.ones_like(modifications)
+    for (layer, channel), magnitude, offset_factor in style_space_modifications:
+        if layer_idx == layer:
+            modifications[:, channel] = magnitude
+            offset_factors[:, channel] = offset_factor
+    return modifications, offset_factors
+
+
+def w_to_s(self, w, weight_gain, style_space_modifications=None, style_space_modifications_first=False,
+           saved_styles=None):
+    """W -> S: optional W-space offset, affine layer, optional S-space offset and edits."""
+    kind = self.domain_modulation_parametrization if self.use_domain_modulation else None
+    if kind == 'multiplicative_w_space':
+        w = (self.ones + self.offset * self.offset_mask) * w
+    elif kind == 'additive_w_space':
+        w = w + self.offset * self.offset_mask
+
+    styles = self.affine(w) * weight_gain
+    if saved_styles is not None:
+        saved_styles['initial'][self.layer_idx] = styles.detach().cpu()
+
+    modifications, offset_factors = get_style_space_modifications(self.layer_idx, styles, style_space_modifications)
+    if style_space_modifications is not None and style_space_modifications_first:
+        styles = styles + modifications
+    if kind in ('multiplicative', 'additive'):
+        mask = self.offset_mask if style_space_modifications is None else self.offset_mask * offset_factors
+        styles = (self.ones + self.offset * mask) * styles if kind == 'multiplicative' else styles + self.offset * mask
+    if style_space_modifications is not None and not style_space_modifications_first:
+        styles = styles + modifications
+    if saved_styles is not None:
+        saved_styles['final'][self.layer_idx] = styles.detach().cpu()
+    return styles
+
+
+def weight_to_weight(self, weight):
+    """Weight with its domain offset applied: W + dW ('..._additive') or (1 + dW) * W."""
+    affine_kind = getattr(self, 'affine_weights_domain_modulation_parametrization', None)
+    conv_kind = getattr(self, 'weights_domain_modulation_parametrization', None)
+    if affine_kind is not None:       # low-rank terms are summed
+        offset = sum(getattr(self, o) @ getattr(self, i) for o, i in zip(self.weights_offset_out, self.weights_offset_in))
+        return weight + offset if affine_kind.endswith('additive') else (self.ones_weights + offset) * weight
+    if conv_kind is not None:
+        if conv_kind in out_in_decomposition_parametrizations:
+            if conv_kind.startswith('out+in'):
+                offset = getattr(self, self.weights_offset_out[0]) + getattr(self, self.weights_offset_in[0])
+            else:                     # low-rank terms are averaged
+                offset = sum(getattr(self, o) @ getattr(self, i)
+                             for o, i in zip(self.weights_offset_out, self.weights_offset_in)) / len(self.weights_offset_out)
+            offset = offset.unsqueeze(2).unsqueeze(3)
+        else:
+            offset = self.weights_offset
+        return weight + offset if conv_kind.endswith('additive') else (self.ones_weights + offset) * weight
+    return weight
+
+
+# ----------------------------------------------------------------------------
+
+@misc.profiled_function
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+@misc.profiled_function
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True):
+    """Weight-modulated (and demodulated) convolution; arguments as the reference's
+    `modulated_conv2d` (training/networks.py:591-668).
+
+    x [N, I, H, W], weight [O, I, kh, kw], styles [N, I], noise broadcastable to the output.
+    fused_modconv=False scales the activations before and after one shared-weight
+    convolution (training); True runs one grouped convolution with per-sample weights.
+    """
+    batch_size = x.shape[0]
+    out_channels, in_channels, kh, kw = weight.shape
+    misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
+    misc.assert_shape(x, [batch_size, in_channels, None, None])
+    misc.assert_shape(styles, [batch_size, in_channels])
+
+    if x.dtype == torch.float16 and demodulate:   # keep float16 products in range
+        weight = weight * (1 / np.sqrt(in_channels * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+
+    dcoefs = None
+    if demodulate:   # rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + eps) without the [N,O,I,k,k] intermediate
+        dcoefs = (styles.square() @ weight.square().sum(dim=[2, 3]).t() + 1e-8).rsqrt()
+
+    if not fused_modconv:
+        x = x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)
+        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+                                            padding=padding, flip_weight=flip_weight)
+        if demodulate and noise is not None:
+            x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1), noise.to(x.dtype))
+        elif demodulate:
+            x = x * dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1)
+        elif noise is not None:
+            x = x.add_(noise.to(x.dtype))
+        return x
+
+    w = weight.unsqueeze(0) * styles.reshape(batch_size, 1, -1, 1, 1)
+    if demodulate:
+        w = w * dcoefs.reshape(batch_size, -1, 1, 1, 1)
+    x = x.reshape(1, -1, *x.shape[2:])
+    w = w.reshape(-1, in_channels, kh, kw)
+    x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
+                                        groups=batch_size, flip_weight=flip_weight)
+    x = x.reshape(batch_size, -1, *x.shape[2:])
+    if noise is not None:
+        x = x.add_(noise)
+    return x
+
+
+# ----------------------------------------------------------------------------
+
+class FullyConnectedLayer(torch.nn.Module):
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = weight_to_weight(self, self.weight.to(x.dtype)) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+
+class Conv2dLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        self.activation = activation
+        self.up = up
+        self.down = down
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format)
+        bias = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(bias) if bias is not None else None
+        else:   # Freeze-D: same names, but buffers
+            self.register_buffer('weight', weight)
+            if bias is not None:
+                self.register_buffer('bias', bias)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
+
+
+class MappingNetwork(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws = z_dim, c_dim, w_dim, num_ws
+        self.num_layers = num_layers
+        self.w_avg_beta = w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        features = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(features[idx], features[idx + 1], activation=activation,
+                                                          lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+        x = None
+        with torch.autograd.profiler.record_function('input'):
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+            with torch.autograd.profiler.record_function('update_w_avg'):
+                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            with torch.autograd.profiler.record_function('broadcast'):
+                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            with torch.autograd.profiler.record_function('truncate'):
+                assert self.w_avg_beta is not None
+                if self.num_ws is None or truncation_cutoff is None:
+                    x = self.w_avg.lerp(x, truncation_psi)
+                else:
+                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class SynthesisLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True,
+                 activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False,
+                 use_domain_modulation=False, domain_modulation_parametrization='multiplicative',
+                 generator_requires_grad_parts=('all',)):
+        super().__init__()
+        self.is_rgb = False
+        self.resolution = resolution
+        self.up = up
+        self.use_noise = use_noise
+        self.activation = activation
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(
+            torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        register_modulation(self, in_channels, w_dim, use_domain_modulation, domain_modulation_parametrization,
+                            generator_requires_grad_parts)
+        self.layer_idx = None
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, **kwargs):
+        assert noise_mode in ['random', 'const', 'none']
+        in_resolution = self.resolution // self.up
+        misc.assert_shape(x, [None, self.weight.shape[1], in_resolution, in_resolution])
+        styles = w_to_s(self, w=w, weight_gain=1.0, **kwargs)
+        weight = weight_to_weight(self, self.weight)
+        noise = None
+        if self.use_noise and noise_mode == 'random':
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        if self.use_noise and noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
+        x = modulated_conv2d(x=x, weight=weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                             resample_filter=self.resample_filter, flip_weight=(self.up == 1),
+                             fused_modconv=fused_modconv)
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
+
+
+class ToRGBLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=1, conv_clamp=None,
+                 channels_last=False, use_domain_modulation=False, domain_modulation_parametrization='multiplicative',
+                 generator_requires_grad_parts=('all',), activation=None, use_noise=None):
+        super().__init__()   # activation / use_noise are accepted and ignored (legacy checkpoints pass them)
+        self.is_rgb = True
+        self.resolution = resolution
+        self.conv_clamp = conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(
+            torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        register_modulation(self, in_channels, w_dim, use_domain_modulation, domain_modulation_parametrization,
+                            generator_requires_grad_parts)
+        self.layer_idx = None
+
+    def forward(self, x, w, fused_modconv=True, noise_mode='random', **kwargs):
+        styles = w_to_s(self, w=w, weight_gain=self.weight_gain, **kwargs)
+        weight = weight_to_weight(self, self.weight)
+        x = modulated_conv2d(x=x, weight=weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+
+
+class SynthesisBlock(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False,
+                 **layer_kwargs):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.w_dim = w_dim
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.is_last = is_last
+        self.architecture = architecture
+        self.use_fp16 = use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_conv = 0
+        self.num_torgb = 0
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        if in_channels != 0:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
+                                        resample_filter=resample_filter, conv_clamp=conv_clamp,
+                                        channels_last=self.channels_last, **layer_kwargs)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution,
+                                    conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+        self.num_conv += 1
+        if is_last or architecture == 'skip':
+            self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, resolution=resolution,
+                                    conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+            self.num_torgb += 1
+        if in_channels != 0 and architecture == 'resnet':
+            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
+                                    resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, **layer_kwargs):
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        w_iter = iter(ws.unbind(dim=1))
+        dtype = LOW_PRECISION_DTYPE if self.use_fp16 and not force_fp32 else torch.float32
+        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if fused_modconv is None:
+            fused_modconv = (not self.training) and (dtype == torch.float32 or int(ws.shape[0]) == 1)
+
+        if self.in_channels == 0:
+            x = self.const.to(dtype=dtype, memory_format=memory_format)
+            x = x.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
+            x = x.to(dtype=dtype, memory_format=memory_format)
+
+        if self.in_channels == 0:
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        elif self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
+            x = y.add_(x)
+        else:
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+
+        if img is not None:
+            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        if self.is_last or self.architecture == 'skip':
+            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            img = img.add_(y) if img is not None else y
+
+        assert x.dtype == dtype
+        assert img is None or img.dtype == torch.float32
+        return x, img
+
+
+class SynthesisNetwork(torch.nn.Module):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0,
+                 **block_kwargs):
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.img_channels = img_channels
+        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
+        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            in_channels = channels_dict[res // 2] if res > 4 else 0
+            block = SynthesisBlock(in_channels, channels_dict[res], w_dim=w_dim, resolution=res,
+                                   img_channels=img_channels, is_last=(res == self.img_resolution),
+                                   use_fp16=(res >= fp16_resolution), **block_kwargs)
+            self.num_ws += block.num_conv
+            if res == self.img_resolution:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+
+    def forward(self, ws, **block_kwargs):
+        block_ws = []
+        with torch.autograd.profiler.record_function('split_ws'):
+            misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+            ws = ws.to(torch.float32)
+            w_idx = 0
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+                w_idx += block.num_conv
+        x = img = None
+        for res, cur_ws in zip(self.block_resolutions, block_ws):
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+        return img
+
+
+class Generator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels,
+                                          **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+        # layer numbering used by style-space edits: conv0, conv1, torgb per block, in module order
+        idx = 0
+        for name, module in self.named_modules():
+            if re.match(r'synthesis.b[0-9]*.conv[0-1]$', name) or re.match(r'synthesis.b[0-9]*.torgb$', name):
+                module.layer_idx = idx
+                idx += 1
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return self.synthesis(ws, **synthesis_kwargs)
+
+
+# ----------------------------------------------------------------------------
+
+class DiscriminatorBlock(torch.nn.Module):
+    def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx,
+                 architecture='resnet', activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None,
+                 use_fp16=False, fp16_channels_last=False, freeze_layers=0, **_):
+        assert in_channels in [0, tmp_channels]
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.first_layer_idx = first_layer_idx
+        self.architecture = architecture
+        self.use_fp16 = use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_layers = 0
+
+        def next_trainable():   # Freeze-D: the first `freeze_layers` layers of D are buffers
+            trainable = (self.first_layer_idx + self.num_layers) >= freeze_layers
+            self.num_layers += 1
+            return trainable
+
+        if in_channels == 0 or architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation,
+                                       trainable=next_trainable(), conv_clamp=conv_clamp,
+                                       channels_last=self.channels_last)
+        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation,
+                                 trainable=next_trainable(), conv_clamp=conv_clamp, channels_last=self.channels_last)
+        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2,
+                                 trainable=next_trainable(), resample_filter=resample_filter, conv_clamp=conv_clamp,
+                                 channels_last=self.channels_last)
+        if architecture == 'resnet':
+            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2,
+                                    trainable=next_trainable(), resample_filter=resample_filter,
+                                    channels_last=self.channels_last)
+
+    def forward(self, x, img, force_fp32=False):
+        dtype = LOW_PRECISION_DTYPE if self.use_fp16 and not force_fp32 else torch.float32
+        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if x is not None:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+            x = x.to(dtype=dtype, memory_format=memory_format)
+        if self.in_channels == 0 or self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            img = img.to(dtype=dtype, memory_format=memory_format)
+            y = self.fromrgb(img)
+            x = x + y if x is not None else y
+            img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
+        if self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x)
+            x = self.conv1(x, gain=np.sqrt(0.5))
+            x = y.add_(x)
+        else:
+            x = self.conv0(x)
+            x = self.conv1(x)
+        assert x.dtype == dtype
+        return x, img
+
+
+class MinibatchStdLayer(torch.nn.Module):
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size = group_size
+        self.num_channels = num_channels
+
+    def forward(self, x):
+        return minibatch_std.minibatch_std(x, self.group_size, self.num_channels)
+
+
+class DiscriminatorEpilogue(torch.nn.Module):
+    def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4,
+                 mbstd_num_channels=1, activation='lrelu', conv_clamp=None, **_):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.cmap_dim = cmap_dim
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.architecture = architecture
+        if architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
+        self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) \
+            if mbstd_num_channels > 0 else None
+        self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation,
+                                conv_clamp=conv_clamp)
+        self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, img, cmap, force_fp32=False):
+        misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+        x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        if self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            x = x + self.fromrgb(img.to(dtype=torch.float32, memory_format=torch.contiguous_format))
+        if self.mbstd is not None:
+            x = self.mbstd(x)
+        x = self.conv(x)
+        x = self.fc(x.flatten(1))
+        x = self.out(x)
+        if self.cmap_dim > 0:
+            misc.assert_shape(cmap, [None, self.cmap_dim])
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+        assert x.dtype == torch.float32
+        return x
+
+
+class Discriminator(torch.nn.Module):
+    def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768,
+                 channel_max=512, num_fp16_res=0, conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={},
+                 epilogue_kwargs={}):
+        super().__init__()
+        self.c_dim = c_dim
+        self.img_resolution = img_resolution
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.img_channels = img_channels
+        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
+        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        if cmap_dim is None:
+            cmap_dim = channels_dict[4]
+        if c_dim == 0:
+            cmap_dim = 0
+        common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        cur_layer_idx = 0
+        for res in self.block_resolutions:
+            in_channels = channels_dict[res] if res < img_resolution else 0
+            block = DiscriminatorBlock(in_channels, channels_dict[res], channels_dict[res // 2], resolution=res,
+                                       first_layer_idx=cur_layer_idx, use_fp16=(res >= fp16_resolution),
+                                       **block_kwargs, **common_kwargs)
+            setattr(self, f'b{res}', block)
+            cur_layer_idx += block.num_layers
+        if c_dim > 0:
+            self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None,
+                                          **mapping_kwargs)
+        self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs,
+                                        **common_kwargs)
+
+    def forward(self, img, c, **block_kwargs):
+        x = None
+        for res in self.block_resolutions:
+            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+        cmap = self.mapping(None, c) if self.c_dim > 0 else None
+        return self.b4(x, img, cmap)

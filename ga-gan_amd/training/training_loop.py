@@ -1,0 +1,316 @@
+"""Few-shot adaptation training loop: phases (Gmain / Greg / Dmain / Dreg with lazy
+regularisation), Adam, generator EMA, and data-parallel gradient exchange.
+
+Implements the behaviour the reference's `training_loop()` is written to have
+(training/training_loop.py:163-538; its loop body is mis-indented there and never
+reaches the optimizer step): per iteration, every phase whose interval divides the
+iteration index zeroes its gradients, enables exactly the parameter groups named by
+`requires_grad_parts`, accumulates gradients over the rounds of `batch_gpu` samples,
+sanitises them and steps its optimizer; then G_ema is updated.
+
+Multi-GPU: one process per GPU; each rank draws its own latents and takes its own
+slice of the real batch; the gradients of the parameters a phase trains are summed
+across ranks (RCCL all-reduce over xGMI via torch.distributed) after the last
+accumulation round and divided by the world size.  Only tensors that received a
+gradient take part, so partially trainable generators (Affine+, AffineLight+) exchange
+a few MB instead of the whole network.
+"""
+import copy
+import time
+
+import numpy as np
+import torch
+
+from ..torch_utils import misc
+from ..torch_utils import training_stats
+from ..torch_utils.ops import conv2d_gradfix
+from . import loss as loss_module
+from . import networks
+
+
+# ----------------------------------------------------------------------------
+# Parameter groups of `--generator-requires-grad-parts` (reference: training_loop.py:33-95).
+
+def check_block_resolution(pname, resolution):
+    return ('synthesis' in pname) if resolution is None else (f'synthesis.b{resolution}' in pname)
+
+
+def _rgb(n):
+    return 'torgb.weight' in n or 'torgb.bias' in n
+
+
+name_filters = {
+    'mapping': lambda res: lambda n: 'mapping' in n,
+    'tRGB_affine': lambda res: lambda n: check_block_resolution(n, res) and 'torgb.affine' in n,
+    'tRGB_conv': lambda res: lambda n: check_block_resolution(n, res) and _rgb(n) and 'affine' not in n and 'offset' not in n,
+    'tRGB_offset': lambda res: lambda n: check_block_resolution(n, res) and 'torgb.offset' in n and 'torgb.weights_offset' not in n,
+    'tRGB_weights_offset': lambda res: lambda n: check_block_resolution(n, res) and 'torgb.weights_offset' in n,
+    'tRGB_affine_weights_offset': lambda res: lambda n: check_block_resolution(n, res) and 'torgb.affine.weights_offset' in n,
+    'synt_affine': lambda res: lambda n: check_block_resolution(n, res) and 'conv' in n and 'affine' in n,
+    'synt_conv': lambda res: lambda n: check_block_resolution(n, res) and 'conv' in n
+    and ('weight' in n or 'noise_strength' in n or 'bias' in n) and 'affine' not in n and 'offset' not in n,
+    'synt_const': lambda res: lambda n: check_block_resolution(n, res) and 'const' in n,
+    'synt_offset': lambda res: lambda n: check_block_resolution(n, res) and 'conv' in n and 'offset' in n and 'weights_offset' not in n,
+    'synt_weights_offset': lambda res: lambda n: check_block_resolution(n, res) and 'conv' in n and 'affine' not in n and 'weights_offset' in n,
+    'synt_affine_weights_offset': lambda res: lambda n: check_block_resolution(n, res) and 'conv' in n and 'affine.weights_offset' in n,
+}
+
+
+def set_requires_grad_by_filter(module, param_filter, verbose=False):
+    for name, param in module.named_parameters():
+        if param_filter(name):
+            param.requires_grad_(True)
+            if verbose:
+                print(f'{name: <60}: {str(list(param.shape)): <30} {param.numel():d}')
+
+
+def set_requires_grad(module, parts, verbose=False):
+    """Freeze everything, then enable the groups in `parts` ('all', '<group>' or '<group>.b<res>')."""
+    assert isinstance(parts, list)
+    module.requires_grad_(False)
+    if 'all' in parts:
+        module.requires_grad_(True)
+        return
+    for name, name_filter in name_filters.items():
+        for resolution in [1024, 512, 256, 128, 64, 32, 16, 8, 4, None]:
+            target = name if resolution is None else f'{name}.b{resolution}'
+            if target in parts:
+                set_requires_grad_by_filter(module, name_filter(resolution), verbose=verbose)
+
+
+# ----------------------------------------------------------------------------
+# Option presets (reference: train.py:219-279, 449-466).
+
+CFG_SPECS = {
+    'stylegan2': dict(ref_gpus=8, kimg=25000, mb=32, mbstd=4, lrate=0.002, gamma=10, ema=10, ramp=None, map=8, fmaps=1),
+    'paper256': dict(ref_gpus=8, kimg=25000, mb=64, mbstd=8, lrate=0.0025, gamma=1, ema=20, ramp=None, map=8, fmaps=0.5),
+    'paper512': dict(ref_gpus=8, kimg=25000, mb=64, mbstd=8, lrate=0.0025, gamma=0.5, ema=20, ramp=None, map=8, fmaps=1),
+    'paper1024': dict(ref_gpus=8, kimg=25000, mb=32, mbstd=4, lrate=0.002, gamma=2, ema=10, ramp=None, map=8, fmaps=1),
+}
+
+AFFINE_PLUS = dict(
+    generator_requires_grad_parts=['synt_affine', 'tRGB_affine', 'synt_weights_offset.b64', 'tRGB_weights_offset.b64'],
+    use_domain_modulation=True, domain_modulation_parametrization='out_in_additive')
+AFFINE_LIGHT_PLUS = dict(
+    generator_requires_grad_parts=['synt_affine_weights_offset', 'tRGB_affine_weights_offset', 'synt_weights_offset.b64',
+                                   'tRGB_weights_offset.b64'],
+    use_domain_modulation=True, domain_modulation_parametrization='out_in_additive,affine_out_in_5_1_additive')
+FULL = dict(generator_requires_grad_parts=['all'], use_domain_modulation=False, domain_modulation_parametrization=None)
+
+
+def setup_training_options(cfg='paper256', resolution=256, batch_size=None, num_gpus=1, batch_gpu=None,
+                           generator_requires_grad_parts=('all',), use_domain_modulation=False,
+                           domain_modulation_parametrization=None, glrate=None, dlrate=None, gamma=None, fp32=False,
+                           mbstd=None, c_dim=0, freezed=None):
+    """Keyword arguments for `Trainer` the way the reference's `train.py` derives them from its flags."""
+    spec = dict(CFG_SPECS[cfg])
+    batch_size = spec['mb'] if batch_size is None else batch_size
+    batch_gpu = batch_size // num_gpus if batch_gpu is None else batch_gpu
+    parts = list(generator_requires_grad_parts)
+    synthesis_kwargs = dict(channel_base=int(spec['fmaps'] * 32768), channel_max=512,
+                            num_fp16_res=0 if fp32 else 4, conv_clamp=None if fp32 else 256,
+                            generator_requires_grad_parts=parts)
+    if use_domain_modulation:
+        synthesis_kwargs.update(use_domain_modulation=True, domain_modulation_parametrization=domain_modulation_parametrization)
+    G_kwargs = dict(z_dim=512, w_dim=512, c_dim=c_dim, img_resolution=resolution, img_channels=3,
+                    mapping_kwargs=dict(num_layers=spec['map']), synthesis_kwargs=synthesis_kwargs)
+    D_kwargs = dict(c_dim=c_dim, img_resolution=resolution, img_channels=3, channel_base=int(spec['fmaps'] * 32768),
+                    channel_max=512, num_fp16_res=0 if fp32 else 4, conv_clamp=None if fp32 else 256,
+                    block_kwargs=dict(freeze_layers=freezed) if freezed else {}, mapping_kwargs={},
+                    epilogue_kwargs=dict(mbstd_group_size=min(spec['mbstd'] if mbstd is None else mbstd, batch_gpu)))
+    lr_g = spec['lrate'] if glrate is None else glrate
+    lr_d = spec['lrate'] if dlrate is None else dlrate
+    return dict(
+        G_kwargs=G_kwargs, D_kwargs=D_kwargs,
+        G_opt_kwargs=dict(lr=lr_g, betas=[0, 0.99], eps=1e-8), D_opt_kwargs=dict(lr=lr_d, betas=[0, 0.99], eps=1e-8),
+        loss_kwargs=dict(r1_gamma=spec['gamma'] if gamma is None else gamma),
+        batch_size=batch_size, batch_gpu=batch_gpu, num_gpus=num_gpus, ema_kimg=spec['ema'], ema_rampup=spec['ramp'],
+        requires_grad_parts={'Gboth': parts, 'Gmain': parts, 'Greg': parts, 'Dboth': ['all'], 'Dmain': ['all'], 'Dreg': ['all']})
+
+
+# ----------------------------------------------------------------------------
+# Gradient exchange.
+
+class GradReducer:
+    """Average the gradients of a parameter list across ranks with as few collectives
+    as possible: gradients are packed into one flat buffer per dtype, all-reduced in
+    buckets of `bucket_bytes` (asynchronously, so packing bucket k+1 overlaps the
+    reduction of bucket k on RCCL's stream), and unpacked in place."""
+
+    def __init__(self, world_size, bucket_bytes=64 << 20, group=None):
+        self.world_size = world_size
+        self.bucket_bytes = bucket_bytes
+        self.group = group
+
+    def __call__(self, params):
+        if self.world_size <= 1:
+            return 0
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return 0
+        buckets, current, size = [], [], 0
+        for g in grads:
+            if current and (size + g.numel() * g.element_size() > self.bucket_bytes or g.dtype != current[0].dtype):
+                buckets.append(current)
+                current, size = [], 0
+            current.append(g)
+            size += g.numel() * g.element_size()
+        buckets.append(current)
+        pending = []
+        for bucket in buckets:
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            work = torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+            pending.append((work, flat, bucket))
+        total = 0
+        for work, flat, bucket in pending:
+            work.wait()
+            flat.div_(self.world_size)
+            offset = 0
+            for g in bucket:
+                g.copy_(flat[offset:offset + g.numel()].view_as(g))
+                offset += g.numel()
+            total += flat.numel() * flat.element_size()
+        return total
+
+
+# ----------------------------------------------------------------------------
+
+class Phase:
+    def __init__(self, name, module, opt, interval):
+        self.name, self.module, self.opt, self.interval = name, module, opt, interval
+
+
+class Trainer:
+    """State and one-iteration step of the training loop, for one rank."""
+
+    def __init__(self, G_kwargs, D_kwargs, G_opt_kwargs, D_opt_kwargs, loss_kwargs=None, batch_size=32, batch_gpu=32,
+                 num_gpus=1, rank=0, ema_kimg=10, ema_rampup=None, G_reg_interval=4, D_reg_interval=16,
+                 requires_grad_parts=None, device=None, random_seed=0, augment_pipe=None, resume=None):
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.rank, self.num_gpus = rank, num_gpus
+        self.batch_size, self.batch_gpu = batch_size, batch_gpu
+        assert batch_size % (batch_gpu * num_gpus) == 0
+        self.ema_kimg, self.ema_rampup = ema_kimg, ema_rampup
+        np.random.seed(random_seed * num_gpus + rank)
+        torch.manual_seed(random_seed * num_gpus + rank)
+        conv2d_gradfix.enabled = True
+
+        # All ranks build identical networks (the constructors draw from a fixed seed).
+        rng_state = torch.get_rng_state()
+        torch.manual_seed(random_seed)
+        self.G = networks.Generator(**G_kwargs).train().requires_grad_(False).to(self.device)
+        self.D = networks.Discriminator(**D_kwargs).train().requires_grad_(False).to(self.device)
+        torch.set_rng_state(rng_state)
+        if resume is not None:
+            for name, module in (('G', self.G), ('D', self.D)):
+                if name in resume:
+                    module.load_state_dict(resume[name], strict=False)
+        self.G_ema = copy.deepcopy(self.G).eval()
+        if resume is not None and 'G_ema' in resume:
+            self.G_ema.load_state_dict(resume['G_ema'], strict=False)
+
+        self.loss = loss_module.StyleGAN2Loss(device=self.device, G_mapping=self.G.mapping,
+                                              G_synthesis=self.G.synthesis, D=self.D, augment_pipe=augment_pipe,
+                                              **(loss_kwargs or {}))
+        self.requires_grad_parts = requires_grad_parts or {k: ['all'] for k in
+                                                           ('Gboth', 'Gmain', 'Greg', 'Dboth', 'Dmain', 'Dreg')}
+        self.reducer = GradReducer(num_gpus)
+        self.phases = []
+        for name, module, opt_kwargs, reg_interval in (('G', self.G, G_opt_kwargs, G_reg_interval),
+                                                       ('D', self.D, D_opt_kwargs, D_reg_interval)):
+            opt_kwargs = dict(opt_kwargs)
+            if reg_interval is None:
+                opt = torch.optim.Adam(module.parameters(), **opt_kwargs)
+                self.phases.append(Phase(name + 'both', module, opt, 1))
+            else:   # lazy regularisation: compensate the optimizer for the extra steps
+                mb_ratio = reg_interval / (reg_interval + 1)
+                opt_kwargs['lr'] = opt_kwargs['lr'] * mb_ratio
+                opt_kwargs['betas'] = [beta ** mb_ratio for beta in opt_kwargs['betas']]
+                opt = torch.optim.Adam(module.parameters(), **opt_kwargs)
+                self.phases.append(Phase(name + 'main', module, opt, 1))
+                self.phases.append(Phase(name + 'reg', module, opt, reg_interval))
+        self.cur_nimg = 0
+        self.batch_idx = 0
+        self.exchanged_bytes = 0
+
+    # -- data ------------------------------------------------------------------
+    def synthetic_batch(self, generator=None):
+        """Uniform random uint8 images of this rank's share of the batch (and empty labels)."""
+        n = self.batch_size // self.num_gpus
+        res = self.G.img_resolution
+        img = torch.randint(0, 256, [n, self.G.img_channels, res, res], dtype=torch.uint8, device=self.device,
+                            generator=generator)
+        return img, torch.zeros([n, self.G.c_dim], device=self.device)
+
+    # -- one iteration ----------------------------------------------------------
+    def step(self, real_img, real_c, gen_z=None):
+        """real_img: this rank's share, uint8 [n, C, H, W] (or float already in [-1, 1])."""
+        n_rank = self.batch_size // self.num_gpus
+        with torch.autograd.profiler.record_function('data_fetch'):
+            real = real_img.to(self.device)
+            if not real.is_floating_point():
+                real = real.to(torch.float32) / 127.5 - 1
+            phase_real_img = real.split(self.batch_gpu)
+            phase_real_c = real_c.to(self.device).split(self.batch_gpu)
+            if gen_z is None:
+                gen_z = torch.randn([len(self.phases) * n_rank, self.G.z_dim], device=self.device)
+            all_gen_z = [z.split(self.batch_gpu) for z in gen_z.split(n_rank)]
+            all_gen_c = [real_c.to(self.device).split(self.batch_gpu) for _ in self.phases]
+        rounds = n_rank // self.batch_gpu
+
+        for phase, phase_gen_z, phase_gen_c in zip(self.phases, all_gen_z, all_gen_c):
+            if self.batch_idx % phase.interval != 0:
+                continue
+            phase.opt.zero_grad(set_to_none=True)
+            set_requires_grad(phase.module, parts=self.requires_grad_parts[phase.name])
+            for round_idx, (r_img, r_c, g_z, g_c) in enumerate(zip(phase_real_img, phase_real_c, phase_gen_z, phase_gen_c)):
+                self.loss.accumulate_gradients(phase=phase.name, real_img=r_img, real_c=r_c, gen_z=g_z, gen_c=g_c,
+                                               sync=(round_idx == rounds - 1), gain=phase.interval)
+            phase.module.requires_grad_(False)
+            with torch.autograd.profiler.record_function(phase.name + '_opt'):
+                params = [p for p in phase.module.parameters() if p.grad is not None]
+                self.exchanged_bytes += self.reducer(params)
+                if params:
+                    grads = [p.grad for p in params]
+                    for g in grads:
+                        misc.nan_to_num_(g)
+                    phase.opt.step()
+
+        with torch.autograd.profiler.record_function('Gema'):
+            ema_nimg = self.ema_kimg * 1000
+            if self.ema_rampup is not None:
+                ema_nimg = min(ema_nimg, self.cur_nimg * self.ema_rampup)
+            ema_beta = 0.5 ** (self.batch_size / max(ema_nimg, 1e-8))
+            with torch.no_grad():
+                ema_params, params = list(self.G_ema.parameters()), list(self.G.parameters())
+                torch._foreach_lerp_(ema_params, params, 1 - ema_beta)     # == p.lerp(p_ema, ema_beta)
+                torch._foreach_copy_(list(self.G_ema.buffers()), list(self.G.buffers()))
+        self.cur_nimg += self.batch_size
+        self.batch_idx += 1
+
+
+def training_loop(total_kimg=1, kimg_per_tick=4, data_iterator=None, progress_fn=None, rank=0, verbose=True,
+                  **trainer_kwargs):
+    """Run `Trainer.step` until `total_kimg` thousand real images have been shown.  `data_iterator`
+    yields (uint8 images, labels) for this rank; None = synthetic images.  Prints one status line per
+    tick (`Timing/sec_per_kimg` as the reference's log does) and returns the trainer."""
+    trainer = Trainer(rank=rank, **trainer_kwargs)
+    tick_start_nimg, tick_start_time, tick = 0, time.time(), 0
+    start_time = tick_start_time
+    while trainer.cur_nimg < total_kimg * 1000:
+        real_img, real_c = next(data_iterator) if data_iterator is not None else trainer.synthetic_batch()
+        trainer.step(real_img, real_c)
+        done = trainer.cur_nimg >= total_kimg * 1000
+        if done or trainer.cur_nimg >= tick_start_nimg + kimg_per_tick * 1000:
+            torch.cuda.synchronize(trainer.device)
+            now = time.time()
+            sec_per_kimg = (now - tick_start_time) / max(trainer.cur_nimg - tick_start_nimg, 1) * 1e3
+            training_stats.report('Timing/sec_per_kimg', sec_per_kimg)
+            if rank == 0 and verbose:
+                print(f'tick {tick:<5d} kimg {trainer.cur_nimg / 1e3:<8.1f} time {now - start_time:<8.1f} '
+                      f'sec/kimg {sec_per_kimg:<8.2f}', flush=True)
+            tick += 1
+            tick_start_nimg, tick_start_time = trainer.cur_nimg, now
+            if progress_fn is not None:
+                progress_fn(trainer.cur_nimg // 1000, total_kimg)
+    return trainer

@@ -1,0 +1,211 @@
+"""GPU parity of the product networks / loss (HIP op path) against the reference's
+outputs stored in tests/golden and against the CPU oracle.  Run with -m gpu.
+
+float32 tolerance: 1e-4 of the tensor's max magnitude for activations, 1e-3 for
+parameter gradients of whole networks (sums over up to 1e5 products in a different
+order than the CPU path); images additionally within 1e-3 relative L2, the bound
+the project states for generated images.
+"""
+import zlib
+
+import pytest
+import torch
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def close(a, b, tol, what=''):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-3)
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, (what, err, scale)
+
+
+def networks():
+    from ga_gan_amd.training import networks as n
+    return n
+
+
+@pytest.mark.parametrize('case', golden_io.load('layers'), ids=lambda c: f"{c.meta['tag']}-{c.meta['kind']}")
+def test_layers(case):
+    n = networks()
+    m = case.meta
+    kw = dict(w_dim=16, resolution=16, conv_clamp=256, use_domain_modulation=m['use_domain_modulation'],
+              domain_modulation_parametrization=m['parametrization'], generator_requires_grad_parts=tuple(m['parts']))
+    if m['kind'] == 'torgb':
+        layer = n.ToRGBLayer(8, 3, **kw)
+    else:
+        layer = n.SynthesisLayer(8, 6, up=2 if m['kind'] == 'conv_up' else 1, **kw)
+    layer.load_state_dict(case.group('sd.'), strict=True)
+    layer.to(DEV)
+    x, w = case.t('x', DEV), case.t('w', DEV)
+    extra = {} if m['kind'] == 'torgb' else dict(gain=0.5 ** 0.5)
+    y = layer(x, w, fused_modconv=False, noise_mode='const')
+    yf = layer(x, w, fused_modconv=True, noise_mode='const', **extra)
+    close(y, case.t('y'), 1e-4, 'y')
+    close(yf, case.t('y_fused'), 1e-4, 'y_fused')
+    want = case.group('g.')
+    params = dict(layer.named_parameters())
+    assert sorted(params) == sorted(want)
+    grads = torch.autograd.grad((y * case.t('dy', DEV)).sum(), [params[k] for k in want], allow_unused=True)
+    for k, g in zip(want, grads):
+        close(g if g is not None else torch.zeros_like(params[k]), want[k], 2e-4, k)
+
+
+NETS = golden_io.load('networks')
+
+
+def build_G(m):
+    n = networks()
+    sk = dict(channel_base=m['channel_base'], channel_max=m['channel_max'], num_fp16_res=0, conv_clamp=m['conv_clamp'],
+              generator_requires_grad_parts=list(m['parts']))
+    if m['parametrization'] is not None:
+        sk.update(use_domain_modulation=True, domain_modulation_parametrization=m['parametrization'])
+    return n.Generator(z_dim=m['z_dim'], c_dim=m['c_dim'], w_dim=m['w_dim'], img_resolution=m['res'], img_channels=3,
+                       mapping_kwargs=dict(num_layers=m['mapping_layers']), synthesis_kwargs=sk)
+
+
+def build_D(m, **extra):
+    n = networks()
+    return n.Discriminator(c_dim=m['c_dim'], img_resolution=m['res'], img_channels=3, architecture=m.get('architecture', 'resnet'),
+                           channel_base=m['channel_base'], channel_max=m['channel_max'], num_fp16_res=0,
+                           conv_clamp=m['conv_clamp'], epilogue_kwargs=dict(mbstd_group_size=m['mbstd_group_size']), **extra)
+
+
+@pytest.mark.parametrize('case', [c for c in NETS if c.meta['kind'] == 'G'], ids=lambda c: c.meta['tag'])
+def test_generator(case):
+    from ga_gan_amd.training import training_loop
+    m = case.meta
+    G = build_G(m)
+    G.load_state_dict(case.group('sd.'), strict=True)
+    G.to(DEV).train()
+    training_loop.set_requires_grad(G, list(m['parts']))
+    assert sorted(k for k, p in G.named_parameters() if p.requires_grad) == sorted(m['trainable'])
+    z, c = case.t('z', DEV), case.t('c', DEV)
+    img = G(z, c, noise_mode='const')
+    close(img, case.t('img'), 1e-4, 'img')
+    assert golden_io.rel_err(img, case.t('img')) < 1e-3
+    close(G.mapping.w_avg, case.t('w_avg_after'), 1e-5, 'w_avg')
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad((img * case.t('dy', DEV)).sum(), [params[k] for k in m['trainable']])
+    want = case.group('g.')
+    for k, g in zip(m['trainable'], grads):
+        close(g, want[k], 1e-3, k)
+    G.eval()
+    with torch.no_grad():
+        close(G(z, c, noise_mode='const', truncation_psi=0.7, truncation_cutoff=3), case.t('img_eval'), 1e-4, 'eval')
+        close(G(z, c, noise_mode='none'), case.t('img_none'), 1e-4, 'none')
+
+
+@pytest.mark.parametrize('case', [c for c in NETS if c.meta['kind'] == 'D'], ids=lambda c: c.meta['tag'])
+def test_discriminator(case):
+    m = case.meta
+    extra = dict(block_kwargs=dict(freeze_layers=3)) if m['tag'] == 'D32_freeze' else {}
+    D = build_D(m, **extra)
+    D.load_state_dict(case.group('sd.'), strict=True)
+    D.to(DEV).train().requires_grad_(True)
+    img = case.t('img', DEV, grad=True)
+    logits = D(img, case.t('c', DEV))
+    close(logits, case.t('logits'), 1e-4, 'logits')
+    want, want2 = case.group('g.'), case.group('g2.')
+    params = dict(D.named_parameters())
+    assert sorted(params) == sorted(want)
+    names = list(want)
+    grads = torch.autograd.grad(logits.sum(), [img] + [params[k] for k in names], create_graph=True)
+    close(grads[0], case.t('gimg'), 1e-4, 'gimg')
+    for k, g in zip(names, grads[1:]):
+        close(g, want[k], 1e-3, k)
+    r1 = grads[0].square().sum()
+    close(r1, case.t('r1'), 1e-3, 'r1')
+    g2 = torch.autograd.grad(r1, [params[k] for k in names], allow_unused=True)
+    for k, g in zip(names, g2):
+        close(g if g is not None else torch.zeros_like(params[k]), want2[k], 2e-3, 'g2.' + k)
+
+
+@pytest.mark.parametrize('case', golden_io.load('loss'), ids=lambda c: c.meta['tag'])
+def test_loss_phases(case):
+    from ga_gan_amd.training import loss as loss_module
+    from ga_gan_amd.training import training_loop
+    m = case.meta
+    m = dict(m, c_dim=0)
+    G, D = build_G(m), build_D(m)
+    G.load_state_dict(case.group('G.'), strict=True)
+    D.load_state_dict(case.group('D.'), strict=True)
+    G.to(DEV).train().requires_grad_(False)
+    D.to(DEV).train().requires_grad_(False)
+    loss = loss_module.StyleGAN2Loss(device=torch.device(DEV), G_mapping=G.mapping, G_synthesis=G.synthesis, D=D,
+                                     style_mixing_prob=0, r1_gamma=m['r1_gamma'], pl_batch_shrink=m['pl_batch_shrink'],
+                                     pl_decay=m['pl_decay'], pl_weight=m['pl_weight'])
+    loss.synthesis_kwargs = dict(noise_mode='const')
+    z, c, real = case.t('z', DEV), case.t('c', DEV), case.t('real', DEV)
+    for phase in ('Gmain', 'Greg', 'Dmain', 'Dreg'):
+        module, parts = (G, list(m['parts'])) if phase[0] == 'G' else (D, ['all'])
+        G.zero_grad(set_to_none=True)
+        D.zero_grad(set_to_none=True)
+        G.requires_grad_(False)
+        D.requires_grad_(False)
+        training_loop.set_requires_grad(module, parts)
+        close(G.mapping.w_avg, case.t(f'{phase}.w_avg_before'), 1e-5, 'w_avg before ' + phase)
+        loss.accumulate_gradients(phase=phase, real_img=real, real_c=c, gen_z=z, gen_c=c, sync=True,
+                                  gain=m['gains'][phase], pl_noise_unit=case.t('pl_noise_unit', DEV))
+        want = case.group(f'{phase}.g.')
+        got = {k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+        assert sorted(got) == sorted(want), phase
+        for k in want:
+            close(got[k], want[k], 2e-3, f'{phase} {k}')
+        close(G.mapping.w_avg, case.t(f'{phase}.w_avg_after'), 1e-5, 'w_avg after ' + phase)
+        close(loss.pl_mean, case.t(f'{phase}.pl_mean_after'), 1e-4, 'pl_mean ' + phase)
+        module.requires_grad_(False)
+
+
+def seeded_fill(name, shape):
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7fffffff)
+    t = torch.randn(list(shape), generator=gen)
+    if name.endswith('noise_strength'):
+        t = t * 0.1
+    elif name.endswith('.bias') and '.affine.' in name:
+        t = t * 0.1 + 1
+    elif name.endswith('.bias') or 'weights_offset' in name or name.endswith('w_avg'):
+        t = t * 0.1
+    return t
+
+
+def full_size_generator(num_fp16_res):
+    from ga_gan_amd.training import training_loop
+    opts = training_loop.setup_training_options(cfg='paper256', resolution=256, batch_size=4, **training_loop.AFFINE_PLUS)
+    kw = opts['G_kwargs']
+    kw['synthesis_kwargs'].update(num_fp16_res=num_fp16_res, conv_clamp=256)
+    G = networks().Generator(**kw)
+    case, = golden_io.load('full_size')
+    sd = G.state_dict()
+    for name, shape in zip(case.meta['names'], case.meta['shapes']):
+        assert list(sd[name].shape) == shape, name
+        sd[name] = seeded_fill(name, shape)
+    G.load_state_dict(sd, strict=True)
+    return G.to(DEV).train(), case
+
+
+def test_full_size_generator_256_fp32():
+    """FFHQ-256 Affine+ generator, batch 1, float32: within 1e-3 relative L2 of the reference's image."""
+    G, case = full_size_generator(num_fp16_res=0)
+    with torch.no_grad():
+        img = G(case.t('z', DEV), torch.zeros(1, 0, device=DEV), noise_mode='const')
+    crop = img[:, :, 120:136, 120:136]
+    assert golden_io.rel_err(crop, case.t('crop')) < 1e-3
+    assert golden_io.rel_err(img.double().sum(dim=[0, 1, 3]), case.t('row_sums')) < 1e-3
+    assert abs(float(img.double().abs().sum()) / float(case.np('abs_sum')) - 1) < 1e-4
+
+
+def test_full_size_generator_256_bf16():
+    """Same generator with the four highest resolutions in bfloat16 (the bench configuration): the image
+    stays within 3e-2 relative L2 of the float32 reference image (bf16 keeps 8 significant bits per layer)."""
+    G, case = full_size_generator(num_fp16_res=4)
+    with torch.no_grad():
+        img = G(case.t('z', DEV), torch.zeros(1, 0, device=DEV), noise_mode='const')
+    assert img.dtype == torch.float32
+    assert golden_io.rel_err(img[:, :, 120:136, 120:136], case.t('crop')) < 3e-2
+    assert golden_io.rel_err(img.double().sum(dim=[0, 1, 3]), case.t('row_sums')) < 3e-2
