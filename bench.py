@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the StyleGAN2 few-shot loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
+
+One "step" is one training iteration of the few-shot loop on synthetic data: Gmain
+and Dmain every iteration, Greg (path length, half batch) every 4th, Dreg (R1) every
+16th, Adam steps, generator EMA - at a fixed per-GPU batch (weak scaling; the global
+batch is per-GPU batch x N).  Default workload: FFHQ-256 Affine+ at batch 32 per GPU
+with the four highest resolutions in bfloat16.  Inputs are resident in HBM before
+the timed region starts.  Rank 0 prints ONE JSON line.
+
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak
+
+CONFIGS = {
+    # name: (description, cfg preset, resolution, per-GPU batch, parameterisation)
+    'c2': ('FFHQ-256 Affine+ bf16, batch=32 per GPU', 'paper256', 256, 32, 'AFFINE_PLUS'),
+    'c3': ('FFHQ-1024 AffineLight+ bf16, batch=16 per GPU', 'stylegan2', 1024, 16, 'AFFINE_LIGHT_PLUS'),
+    'c5': ('AFHQ-512 Affine+ bf16, batch=8 per GPU', 'stylegan2', 512, 8, 'AFFINE_PLUS'),
+    'c4': ('FFHQ-1024 full-generator fine-tune bf16, batch=8 per GPU', 'stylegan2', 1024, 8, 'FULL'),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def make_trainer(args, rank, world):
+    from ga_gan_amd.training import training_loop
+    desc, cfg, res, batch_gpu, par = CONFIGS[args.config]
+    opts = training_loop.setup_training_options(cfg=cfg, resolution=res, batch_size=batch_gpu * world, num_gpus=world,
+                                                batch_gpu=batch_gpu, glrate=0.02 if par != 'FULL' else None,
+                                                **getattr(training_loop, par))
+    return training_loop.Trainer(rank=rank, random_seed=0, **opts), desc, res, batch_gpu
+
+
+def kernel_roofline(trainer, real, real_c, steps):
+    """Instrumented pass: HIP events around every launch of the hand-written kernels (on the stream
+    they are launched on), grouped by kernel; the kernel with the largest total time is reported
+    with its algorithmic bytes (operands read once + result written once) per launch."""
+    from ga_gan_amd import _lib
+    _lib.profile_begin()
+    for _ in range(steps):
+        trainer.step(real, real_c)
+    records = _lib.profile_end()
+    if not records:
+        return None, {}
+    by_kernel = {}
+    for name, nbytes, ms, _flops in records:
+        k = by_kernel.setdefault(name, dict(launches=0, bytes=0, ms=0.0))
+        k['launches'] += 1
+        k['bytes'] += nbytes
+        k['ms'] += ms
+    name, k = max(by_kernel.items(), key=lambda kv: kv[1]['ms'])
+    avg_ms = k['ms'] / k['launches']
+    achieved = (k['bytes'] / k['launches']) / (avg_ms * 1e-3) / 1e9
+    roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None, launches=k['launches'],
+                    avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
+    summary = {n: dict(launches=v['launches'], total_ms=round(v['ms'], 3),
+                       gbps=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)) for n, v in by_kernel.items()}
+    return roofline, summary
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference's fallback path) on this host's cores: FFHQ-256 Affine+,
+    batch 4, float32.  Bounded sample: one Gmain warm-up, then one timed pass of each phase; an average
+    iteration costs Gmain + Dmain + Greg/4 + Dreg/16."""
+    from ga_gan_amd.training import networks, training_loop
+    from oracle import objectives
+    from oracle import stylegan2 as sg
+    cores = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))
+    torch.set_num_threads(cores)
+    opts = training_loop.setup_training_options(cfg='paper256', resolution=256, batch_size=4, fp32=True,
+                                                **training_loop.AFFINE_PLUS)
+    torch.manual_seed(0)
+    G = networks.Generator(**opts['G_kwargs'])
+    D = networks.Discriminator(**opts['D_kwargs'])
+    gp = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    dp = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    g_names = objectives.select_trainable([n for n, _ in G.named_parameters()], opts['requires_grad_parts']['Gmain'])
+    d_names = [n for n, _ in D.named_parameters()]
+    del G, D
+    gcfg = sg.GeneratorConfig(img_resolution=256, channel_base=16384, use_domain_modulation=True,
+                              domain_modulation_parametrization='out_in_additive')
+    dcfg = sg.DiscriminatorConfig(img_resolution=256, channel_base=16384, mbstd_group_size=4)
+    obj = objectives.TrainingObjective(gp, gcfg, dp, dcfg, r1_gamma=1.0)
+    z = torch.randn(4, 512, generator=torch.Generator().manual_seed(0))
+    c = torch.zeros(4, 0)
+    real = torch.randint(0, 256, [4, 3, 256, 256], generator=torch.Generator().manual_seed(1)).float() / 127.5 - 1
+    times = {}
+    for phase, gain in (('warm', 1), ('Gmain', 1), ('Dmain', 1), ('Greg', 4), ('Dreg', 16)):
+        name = 'Gmain' if phase == 'warm' else phase
+        params, names = (gp, g_names) if name[0] == 'G' else (dp, d_names)
+        for t in list(gp.values()) + list(dp.values()):
+            t.requires_grad_(False)
+            t.grad = None
+        for n in names:
+            params[n].requires_grad_(True)
+        t0 = time.perf_counter()
+        obj.accumulate_gradients(name, real, c, z, c, gain)
+        times[phase] = time.perf_counter() - t0
+    per_iter = times['Gmain'] + times['Dmain'] + times['Greg'] / 4 + times['Dreg'] / 16
+    return dict(value=round(4 / per_iter, 4), unit='img/s', cores=cores, kind='port',
+                sample='FFHQ-256 Affine+ batch 4 fp32 on CPU: 1 warm-up + one pass of each phase '
+                       '(Gmain %.2fs, Dmain %.2fs, Greg %.2fs, Dreg %.2fs); iteration = Gmain+Dmain+Greg/4+Dreg/16'
+                       % (times['Gmain'], times['Dmain'], times['Greg'], times['Dreg']))
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no GPU is visible')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run'
+    torch.backends.cudnn.benchmark = os.environ.get('SG_MIOPEN_FIND', '0') == '1'
+
+    from ga_gan_amd.torch_utils import training_stats
+    trainer, desc, res, batch_gpu = make_trainer(args, rank, world)
+    gen = torch.Generator(device=trainer.device).manual_seed(1 + rank)
+    real, real_c = trainer.synthetic_batch(gen)          # resident in HBM before timing
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):   # progress on stderr (the JSON line is the only thing on stdout)
+        if rank == 0:
+            print(f'[bench +{time.perf_counter() - t_start:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    note(f'{desc}; world {world}; warm-up {args.warmup} steps')
+    for i in range(args.warmup):
+        trainer.step(real, real_c)
+        torch.cuda.synchronize()
+        note(f'warm-up step {i} done')
+    barrier()
+    note(f'timing {args.steps} steps')
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(real, real_c)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=trainer.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+
+    note(f'timed region: {elapsed:.3f}s')
+    roofline, kernels = (None, {})
+    if not args.no_roofline:
+        roofline, kernels = kernel_roofline(trainer, real, real_c, min(args.steps, 4))
+        barrier()
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        training_stats.enable(False)
+        note('CPU baseline (oracle) ...')
+        baseline = cpu_baseline()
+        note('CPU baseline done')
+
+    if rank == 0:
+        global_batch = batch_gpu * world
+        out = dict(metric='training images/sec', value=round(args.steps * global_batch / elapsed, 3), unit='img/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
+                   config=dict(workload=desc, resolution=res, global_batch=global_batch, per_gpu_batch=batch_gpu,
+                               parallelism=f'dp{world}', iteration='Gmain+Dmain every step, Greg every 4th, Dreg every 16th',
+                               conv_backend='MIOpen via torch (3x3/1x1 contractions); upfirdn2d, bias_act, minibatch-std: HIP'),
+                   roofline=roofline, cpu_baseline=baseline, kernels=kernels,
+                   grad_exchange_bytes_per_step=int(trainer.exchanged_bytes / max(trainer.batch_idx, 1)))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

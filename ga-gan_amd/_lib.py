@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsgops.so')
 
 SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
-           'sg_mbstd_forward', 'sg_mbstd_backward')
+           'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -64,6 +64,8 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = [ctypes.POINTER(struct), vp]
             fn.restype = ctypes.c_int
+        handle.sg_conv2d.argtypes = [vp, vp]      # struct declared in conv2d_plugin.py
+        handle.sg_conv2d.restype = ctypes.c_int
         _lib = handle
     return _lib
 
@@ -87,3 +89,41 @@ def stream_of(t):
 
 def ptr(t):
     return vp(t.data_ptr()) if t is not None and t.numel() > 0 else vp(None)
+
+
+# ---- launching and per-launch timing -------------------------------------------------
+_profile = None
+
+
+def profile_begin():
+    """Start recording one (label, algorithmic bytes, HIP event pair) entry per kernel launch.
+    The events are recorded on the stream the kernel is enqueued on."""
+    global _profile
+    _profile = []
+
+
+def profile_end():
+    """Stop recording; returns [(label, bytes, milliseconds, flops)] after synchronising."""
+    global _profile
+    records, _profile = _profile or [], None
+    torch.cuda.synchronize()
+    return [(label, nbytes, start.elapsed_time(end), flops) for label, nbytes, start, end, flops in records]
+
+
+def launch(fn_name, params, ref, label=None, nbytes=0, flops=0.0):
+    """Call entry point `fn_name(params*, stream)` on ref's device and current stream."""
+    fn = getattr(lib(), fn_name)
+    with torch.cuda.device(ref.device):
+        if _profile is None:
+            rc = fn(ctypes.byref(params), stream_of(ref))
+        else:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            rc = fn(ctypes.byref(params), stream_of(ref))
+            end.record()
+            _profile.append((label or fn_name, nbytes, start, end, flops))
+    check(rc, fn_name)
+
+
+def nbytes(*tensors):
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)

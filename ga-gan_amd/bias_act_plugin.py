@@ -2,8 +2,6 @@
 `bias_act_plugin` (torch_utils/ops/bias_act.cpp:32, bound at :94-97), executed by the
 gfx950 kernel behind `sg_bias_act`.  "Absent" tensors are passed as empty tensors, as
 the reference's Python wrapper does (torch_utils/ops/bias_act.py:67,186-196)."""
-import ctypes
-
 import torch
 
 from . import _lib
@@ -57,6 +55,5 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
         x=_lib.ptr(x), b=_lib.ptr(b), xref=_lib.ptr(xref), yref=_lib.ptr(yref), dy=_lib.ptr(dy), y=_lib.ptr(y),
         dtype=_lib.dtype_code(x), grad=grad, act=act, alpha=alpha, gain=gain, clamp=clamp,
         size_x=x.numel(), size_b=b.numel(), step_b=x.stride(dim) if b.numel() else 1)
-    with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().sg_bias_act(ctypes.byref(p), _lib.stream_of(x)), 'sg_bias_act')
+    _lib.launch('sg_bias_act', p, x, f'bias_act[act{act} grad{grad}]', _lib.nbytes(x, xref, yref, dy, y))
     return y

@@ -1,0 +1,133 @@
+"""Binding of `sg_conv2d` (include/sg_ops.h): implicit-GEMM convolution on the matrix
+cores with optional per-sample input / output scales, noise, bias, leaky-ReLU, gain and
+clamp fused in.  A `Plan` describes the geometry (plain, strided or transposed in
+polyphase form) and how the weight tensor is packed for it."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Phase(ctypes.Structure):
+    _fields_ = [('oy0', ctypes.c_int32), ('ox0', ctypes.c_int32), ('dy0', ctypes.c_int32), ('dx0', ctypes.c_int32),
+                ('nky', ctypes.c_int32), ('nkx', ctypes.c_int32), ('w_offset', ctypes.c_int64)]
+
+
+class Conv2dParams(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                ('in_scale', ctypes.c_void_p), ('out_scale', ctypes.c_void_p), ('bias', ctypes.c_void_p),
+                ('noise', ctypes.c_void_p), ('noise_gain', ctypes.c_void_p), ('noise_stride_n', ctypes.c_int64),
+                ('dtype', ctypes.c_int32),
+                ('n', ctypes.c_int32), ('ci', ctypes.c_int32), ('h', ctypes.c_int32), ('w_in', ctypes.c_int32),
+                ('co', ctypes.c_int32), ('oh', ctypes.c_int32), ('ow', ctypes.c_int32),
+                ('in_step', ctypes.c_int32), ('out_step', ctypes.c_int32), ('num_phases', ctypes.c_int32),
+                ('phase', Phase * 4),
+                ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float)]
+
+
+class Plan:
+    """Geometry of one convolution.  `phases` = [(oy0, ox0, dy0, dx0, nky, nkx, ky_index, kx_index)] where
+    ky_index / kx_index list, per kernel tap, which row / column of the ordinary weight tensor it uses."""
+
+    def __init__(self, kind, kh, kw, in_step, out_step, phases, out_size):
+        self.kind, self.kh, self.kw = kind, kh, kw
+        self.in_step, self.out_step = in_step, out_step
+        self.phases = phases
+        self.out_size = out_size          # (h, w) -> (oh, ow)
+
+    def pack(self, w, transposed_layout=False):
+        """w [co, ci, kh, kw] (or [ci, co, kh, kw] when transposed_layout) -> flat packed
+        [phase][ky][kx][co][ci] in w's dtype."""
+        if transposed_layout:
+            w = w.transpose(0, 1)
+        parts = []
+        for (_, _, _, _, nky, nkx, ky_idx, kx_idx) in self.phases:
+            sel = w[:, :, ky_idx][:, :, :, kx_idx] if (list(ky_idx) != list(range(self.kh)) or
+                                                        list(kx_idx) != list(range(self.kw))) else w
+            parts.append(sel.permute(2, 3, 0, 1).reshape(-1))
+        return torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
+
+
+def plan_conv(kh, kw, stride=1, padding=0):
+    """Correlation (what torch's conv2d computes) with symmetric zero padding."""
+    def out_size(h, w):
+        return (h + 2 * padding - kh) // stride + 1, (w + 2 * padding - kw) // stride + 1
+    phases = [(0, 0, -padding, -padding, kh, kw, list(range(kh)), list(range(kw)))]
+    return Plan('conv', kh, kw, stride, 1, phases, out_size)
+
+
+def plan_conv_transpose(kh, kw, stride=2, padding=0):
+    """torch's conv_transpose2d(x, w[ci, co, kh, kw], stride, padding) in polyphase form: output row
+    oy = py + stride * a gathers taps ky = r + stride * j with r = (py + padding) % stride from input rows
+    a + (py + padding - r) / stride - j."""
+    def axis(k, phase):
+        r = (phase + padding) % stride
+        taps = list(range(r, k, stride))
+        count = len(taps)
+        d0 = (phase + padding - r) // stride - (count - 1)
+        return count, d0, taps[::-1]      # kernel tap t uses weight index taps[count-1-t]
+
+    def out_size(h, w):
+        return (h - 1) * stride + kh - 2 * padding, (w - 1) * stride + kw - 2 * padding
+
+    phases = []
+    for py in range(stride):
+        for px in range(stride):
+            nky, dy0, ky_idx = axis(kh, py)
+            nkx, dx0, kx_idx = axis(kw, px)
+            if nky and nkx:
+                phases.append((py, px, dy0, dx0, nky, nkx, ky_idx, kx_idx))
+    return Plan('conv_transpose', kh, kw, 1, stride, phases, out_size)
+
+
+ACT_INDEX = {'linear': 1, 'lrelu': 3}
+
+
+def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
+           act='linear', alpha=0.2, gain=1.0, clamp=-1.0):
+    """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow]."""
+    if not x.is_cuda:
+        raise RuntimeError('x must reside on CUDA device')
+    if x.dim() != 4 or not x.is_contiguous():
+        raise RuntimeError('x must be a dense NCHW tensor of rank 4')
+    if w_packed.dtype != x.dtype or w_packed.device != x.device or not w_packed.is_contiguous():
+        raise RuntimeError('packed weights must be dense and have the dtype and device of x')
+    n, ci, h, w = x.shape
+    oh, ow = plan.out_size(h, w)
+    if oh < 1 or ow < 1:
+        raise RuntimeError('output must be at least 1x1')
+    expect = sum(ph[4] * ph[5] for ph in plan.phases) * co * ci
+    if w_packed.numel() != expect:
+        raise RuntimeError(f'packed weights have {w_packed.numel()} elements, the plan needs {expect}')
+    for name, t, shape in (('in_scale', in_scale, (n, ci)), ('out_scale', out_scale, (n, co))):
+        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous()):
+            raise RuntimeError(f'{name} must be a dense float32 tensor of shape {shape}')
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != co or not bias.is_contiguous()):
+        raise RuntimeError('bias must be dense, of x\'s dtype, with one entry per output channel')
+    noise_stride = 0
+    if noise is not None:
+        if noise.dtype != torch.float32 or not noise.is_contiguous() or tuple(noise.shape[-2:]) != (oh, ow):
+            raise RuntimeError('noise must be dense float32 [.., oh, ow]')
+        if noise.numel() == n * oh * ow and n > 1:
+            noise_stride = oh * ow
+        elif noise.numel() != oh * ow:
+            raise RuntimeError('noise must hold one plane, or one plane per sample')
+    if noise_gain is not None and (noise_gain.dtype != torch.float32 or noise_gain.numel() != 1):
+        raise RuntimeError('noise_gain must be a float32 scalar tensor')
+    y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device)
+    if y.numel() == 0:
+        return y
+    p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(w_packed), y=_lib.ptr(y), in_scale=_lib.ptr(in_scale),
+                     out_scale=_lib.ptr(out_scale), bias=_lib.ptr(bias), noise=_lib.ptr(noise),
+                     noise_gain=_lib.ptr(noise_gain), noise_stride_n=noise_stride, dtype=_lib.dtype_code(x),
+                     n=n, ci=ci, h=h, w_in=w, co=co, oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step,
+                     num_phases=len(plan.phases), act=ACT_INDEX[act], alpha=alpha, gain=gain, clamp=clamp)
+    offset = 0
+    for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
+        p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
+        offset += nky * nkx * co * ci
+    taps = sum(ph[4] * ph[5] for ph in plan.phases)
+    label = f'conv2d[{plan.kind} {plan.kh}x{plan.kw} in{plan.in_step} out{plan.out_step} {ci}->{co} @{oh}]'
+    _lib.launch('sg_conv2d', p, x, label, _lib.nbytes(x, y), flops=2.0 * n * co * ci * taps * (oh * ow) / len(plan.phases))
+    return y

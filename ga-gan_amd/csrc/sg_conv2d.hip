@@ -1,0 +1,321 @@
+// Implicit-GEMM 2-D convolution on the matrix cores, with the StyleGAN2 layer fused
+// around it:   y = clamp(act((conv(x * in_scale[n, ci], W) * out_scale[n, co]
+//                              + noise * noise_gain + bias[co])) * gain)
+// One launch covers the modulated 3x3 convolution of a synthesis layer (in_scale =
+// styles, out_scale = demodulation coefficients), a plain discriminator layer (no
+// scales), the 1x1 to-RGB / from-RGB contractions, strided and transposed (polyphase)
+// convolutions, and - with transposed weights and the two scales exchanged - the data
+// gradient of any of them.
+//
+// GEMM view per image: M = output channels, N = output pixels, K = input channels x
+// taps.  A workgroup (4 waves) owns BM output channels x 256 output pixels (IMGS x TH
+// x TW).  The K loop walks the input channels in chunks of 64 bytes per pixel (32
+// bf16/f16 or 16 f32 channels):
+//   * the input footprint of the pixel tile (with its filter halo) is read from the
+//     NCHW tensor with row-contiguous loads, multiplied by in_scale and written to LDS
+//     as [pixel][channel-chunk], so that a lane's 8 (4) consecutive K values are one
+//     16-byte LDS read;
+//   * the weight chunk [tap][BM][channel-chunk] is copied to LDS with 16-byte accesses
+//     from the pre-packed weight tensor [phase][ky][kx][co][ci];
+//   * every wave then issues, per tap, BM/16 A reads + 4 B reads and BM/16 x 4 MFMAs
+//     (v_mfma_f32_16x16x32 for 16-bit types, 4 x v_mfma_f32_16x16x4_f32 for float).
+// Pixel rows are padded to 80 bytes in LDS so that the 16 lanes of a read group fall
+// on different 16-byte bank slots.  Accumulation is float; the epilogue runs on the
+// accumulators and stores once.
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kPitch = 80;        // bytes per LDS pixel row: 64 payload + 16 pad
+constexpr int kChunkBytes = 64;   // K payload per pixel per chunk
+constexpr int kPixels = 256;      // output pixels per workgroup
+constexpr int kThreads = 256;
+
+template <class T> struct Mma;
+template <> struct Mma<__hip_bfloat16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<__half> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane group g = lane >> 4 holds channels 4g .. 4g+3 of the chunk for both operands
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    }
+};
+
+struct Tile {
+    int tw, th, imgs;     // pixel tile in phase coordinates; tw * th * imgs == 256
+    int tw_shift, th_shift;
+    int lw, lh;           // LDS footprint of one image's tile (pixels)
+    int tiles_a, tiles_b, tiles_img;
+};
+
+template <class T, int M_TILES>
+__global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_params p, Tile t) {
+    using S = float;
+    constexpr int KCH = kChunkBytes / (int)sizeof(T);   // channels per chunk
+    constexpr int BM = 16 * M_TILES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+
+    // ---- which tile ------------------------------------------------------------------
+    const int phase = blockIdx.z;
+    const sg_conv2d_phase ph = p.phase[phase];
+    const int AH = (p.oh - ph.oy0 + p.out_step - 1) / p.out_step;   // phase-local output extent
+    const int AW = (p.ow - ph.ox0 + p.out_step - 1) / p.out_step;
+    int tile = blockIdx.x;
+    const int tb = tile % t.tiles_b; tile /= t.tiles_b;
+    const int ta = tile % t.tiles_a; tile /= t.tiles_a;
+    const int img0 = tile * t.imgs;
+    const int a0 = ta * t.th, b0 = tb * t.tw;
+    if (a0 >= AH || b0 >= AW) return;
+    const int m0 = blockIdx.y * BM;
+    const int taps = ph.nky * ph.nkx;
+    const int lw = (t.tw - 1) * p.in_step + ph.nkx;
+    const int lh = (t.th - 1) * p.in_step + ph.nky;
+    const int in_pixels = t.imgs * lh * lw;
+    const int iy0 = a0 * p.in_step + ph.dy0, ix0 = b0 * p.in_step + ph.dx0;
+
+    unsigned char* s_in = smem;
+    unsigned char* s_w = smem + (size_t)t.imgs * t.lh * t.lw * kPitch;   // sized for the largest phase
+
+    const T* __restrict__ x = (const T*)p.x;
+    const T* __restrict__ w = (const T*)p.w + (int64_t)ph.w_offset;
+
+    // ---- per-lane pixel slots of the wave's four n-tiles -----------------------------------
+    int b_addr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = wave * 64 + j * 16 + lrow;
+        const int rb = slot & (t.tw - 1);
+        const int ra = (slot >> t.tw_shift) & (t.th - 1);
+        const int ri = slot >> (t.tw_shift + t.th_shift);
+        b_addr[j] = ((ri * lh + ra * p.in_step) * lw + rb * p.in_step) * kPitch + lgrp * 16;
+    }
+    const int a_addr = lrow * kPitch + lgrp * 16;
+
+    f32x4_t acc[M_TILES][4];
+#pragma unroll
+    for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const bool w_vec = (p.ci % (16 / (int)sizeof(T)) == 0);
+    const int64_t plane = (int64_t)p.h * p.w_in;
+
+    for (int c0 = 0; c0 < p.ci; c0 += KCH) {
+        __syncthreads();   // everyone is done reading the previous chunk
+        // ---- stage the input footprint: [pixel][channel], scaled ------------------------------
+        // A lane owns pixels (coalesced along x) and walks the chunk's channels; the pixel's
+        // coordinates are decoded once per chunk, a channel step is one pointer increment.
+        for (int pix = tid; pix < in_pixels; pix += kThreads) {
+            const int rx = pix % lw;
+            const int ry = (pix / lw) % lh;
+            const int ri = pix / (lw * lh);
+            const int iy = iy0 + ry, ix = ix0 + rx, n = img0 + ri;
+            const bool inside = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w_in && n < p.n;
+            unsigned char* dst = s_in + pix * kPitch;
+            if (!inside) {
+#pragma unroll
+                for (int q = 0; q < kChunkBytes / 16; q++) *reinterpret_cast<uint4*>(dst + q * 16) = make_uint4(0, 0, 0, 0);
+                continue;
+            }
+            const T* src = x + ((int64_t)n * p.ci + c0) * plane + (int64_t)iy * p.w_in + ix;
+            const float* sc = p.in_scale ? p.in_scale + (int64_t)n * p.ci + c0 : nullptr;
+            const int left = p.ci - c0;   // channels that exist from c0 on
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll 4
+                for (int cp = 0; cp < KCH / 2; cp++) {
+                    const int c = 2 * cp;
+                    T h0 = Elem<T>::store(0), h1 = Elem<T>::store(0);
+                    if (c < left) h0 = src[(int64_t)c * plane];
+                    if (c + 1 < left) h1 = src[(int64_t)(c + 1) * plane];
+                    if (sc) {
+                        if (c < left) h0 = Elem<T>::store(Elem<T>::load(h0) * sc[c]);
+                        if (c + 1 < left) h1 = Elem<T>::store(Elem<T>::load(h1) * sc[c + 1]);
+                    }
+                    *reinterpret_cast<unsigned*>(dst + cp * 4) =
+                        (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                }
+            } else {
+#pragma unroll 4
+                for (int c = 0; c < KCH; c++) {
+                    S v = 0;
+                    if (c < left) {
+                        v = Elem<T>::load(src[(int64_t)c * plane]);
+                        if (sc) v *= sc[c];
+                    }
+                    *reinterpret_cast<float*>(dst + c * 4) = v;
+                }
+            }
+        }
+        // ---- stage the weight chunk: [tap][BM][channel] ----------------------------------------
+        if (w_vec) {
+            for (int e = tid; e < taps * BM * 4; e += kThreads) {
+                const int q = e & 3, row = e >> 2;               // row = tap * BM + o
+                const int o = row % BM, tap = row / BM;
+                const int c = c0 + q * (16 / (int)sizeof(T));
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (m0 + o < p.co && c < p.ci)
+                    v = *reinterpret_cast<const uint4*>(w + ((int64_t)tap * p.co + m0 + o) * p.ci + c);
+                *reinterpret_cast<uint4*>(s_w + row * kPitch + q * 16) = v;
+            }
+        } else {
+            for (int e = tid; e < taps * BM * KCH; e += kThreads) {
+                const int cc = e % KCH, row = e / KCH;
+                const int o = row % BM, tap = row / BM;
+                T v = Elem<T>::store(0);
+                if (m0 + o < p.co && c0 + cc < p.ci) v = w[((int64_t)tap * p.co + m0 + o) * p.ci + c0 + cc];
+                *reinterpret_cast<T*>(s_w + row * kPitch + cc * sizeof(T)) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- multiply --------------------------------------------------------------------------
+        for (int ky = 0; ky < ph.nky; ky++) {
+            for (int kx = 0; kx < ph.nkx; kx++) {
+                const int tap = ky * ph.nkx + kx;
+                uint4 a[M_TILES];
+#pragma unroll
+                for (int m = 0; m < M_TILES; m++)
+                    a[m] = *reinterpret_cast<const uint4*>(s_w + (tap * BM + m * 16) * kPitch + a_addr);
+                const int tap_off = (ky * lw + kx) * kPitch;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint4 b = *reinterpret_cast<const uint4*>(s_in + b_addr[j] + tap_off);
+#pragma unroll
+                    for (int m = 0; m < M_TILES; m++) Mma<T>::run(a[m], b, acc[m][j]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: scale, noise, bias, activation, gain, clamp; one store per element ----------
+    const S noise_gain = (p.noise && p.noise_gain) ? *p.noise_gain : (S)1;
+    T* __restrict__ y = (T*)p.y;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = wave * 64 + j * 16 + lrow;
+        const int rb = slot & (t.tw - 1);
+        const int ra = (slot >> t.tw_shift) & (t.th - 1);
+        const int n = img0 + (slot >> (t.tw_shift + t.th_shift));
+        const int a = a0 + ra, b = b0 + rb;
+        if (a >= AH || b >= AW || n >= p.n) continue;
+        const int oy = ph.oy0 + a * p.out_step, ox = ph.ox0 + b * p.out_step;
+        S nz = 0;
+        if (p.noise) nz = p.noise[(int64_t)n * p.noise_stride_n + (int64_t)oy * p.ow + ox] * noise_gain;
+#pragma unroll
+        for (int m = 0; m < M_TILES; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ch = m0 + m * 16 + lgrp * 4 + r;
+                if (ch >= p.co) continue;
+                S v = acc[m][j][r];
+                if (p.out_scale) v *= p.out_scale[(int64_t)n * p.co + ch];
+                v += nz;
+                if (p.bias) v += Elem<T>::load(((const T*)p.bias)[ch]);
+                if (p.act == 3) v = (v > 0) ? v : v * p.alpha;
+                v *= p.gain;
+                if (p.clamp >= 0) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+                y[(((int64_t)n * p.co + ch) * p.oh + oy) * p.ow + ox] = Elem<T>::store(v);
+            }
+        }
+    }
+}
+
+int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v) s++;
+    return s;
+}
+
+template <class T>
+int launch(const sg_conv2d_params& p, hipStream_t stream) {
+    // Phase-local output extent (largest phase) decides the pixel tile.
+    int AH = 0, AW = 0, max_taps = 0, max_nky = 0, max_nkx = 0;
+    for (int i = 0; i < p.num_phases; i++) {
+        const sg_conv2d_phase& ph = p.phase[i];
+        AH = max(AH, (p.oh - ph.oy0 + p.out_step - 1) / p.out_step);
+        AW = max(AW, (p.ow - ph.ox0 + p.out_step - 1) / p.out_step);
+        max_taps = max(max_taps, ph.nky * ph.nkx);
+        max_nky = max(max_nky, ph.nky);
+        max_nkx = max(max_nkx, ph.nkx);
+    }
+    Tile t;
+    t.tw = 32;
+    while (t.tw > 1 && t.tw / 2 >= AW) t.tw /= 2;              // smallest power of two covering AW, at most 32
+    int rest = kPixels / t.tw;
+    t.th = (p.in_step == 1) ? 8 : 4;
+    if (t.th > rest) t.th = rest;
+    while (t.th > 1 && t.th / 2 >= AH) t.th /= 2;
+    t.imgs = rest / t.th;
+    t.tw_shift = ilog2(t.tw);
+    t.th_shift = ilog2(t.th);
+    t.lw = (t.tw - 1) * p.in_step + max_nkx;
+    t.lh = (t.th - 1) * p.in_step + max_nky;
+    t.tiles_b = (AW + t.tw - 1) / t.tw;
+    t.tiles_a = (AH + t.th - 1) / t.th;
+    t.tiles_img = (p.n + t.imgs - 1) / t.imgs;
+
+    const int m_tiles = (p.co > 16) ? 4 : 1;
+    const int BM = 16 * m_tiles;
+    const size_t lds = (size_t)t.imgs * t.lh * t.lw * kPitch + (size_t)max_taps * BM * kPitch;
+    SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
+    const int64_t tiles = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img;
+    SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
+    dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)p.num_phases);
+    auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
+    if (lds > 64 * 1024) {   // opt in to large dynamic LDS (idempotent, cheap)
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, p, t);
+    return check_launch("sg_conv2d");
+}
+
+}  // namespace
+}  // namespace sg
+
+extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
+    using namespace sg;
+    SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
+    SG_REQUIRE(p->n >= 0 && p->ci >= 1 && p->co >= 1 && p->h >= 1 && p->w_in >= 1 && p->oh >= 1 && p->ow >= 1,
+               SG_ERR_INVALID_ARGUMENT, "conv2d: bad tensor sizes");
+    SG_REQUIRE(p->in_step >= 1 && p->in_step <= 2 && p->out_step >= 1 && p->out_step <= 2, SG_ERR_INVALID_ARGUMENT,
+               "conv2d: in_step and out_step must be 1 or 2");
+    SG_REQUIRE(p->num_phases >= 1 && p->num_phases <= 4, SG_ERR_INVALID_ARGUMENT, "conv2d: 1..4 phases");
+    for (int i = 0; i < p->num_phases; i++) {
+        const sg_conv2d_phase& ph = p->phase[i];
+        SG_REQUIRE(ph.nky >= 1 && ph.nkx >= 1 && ph.nky * ph.nkx <= 16, SG_ERR_INVALID_ARGUMENT,
+                   "conv2d: phase %d has %dx%d taps (at most 16 in total)", i, ph.nky, ph.nkx);
+        SG_REQUIRE(ph.oy0 >= 0 && ph.ox0 >= 0 && ph.oy0 < p->out_step && ph.ox0 < p->out_step && ph.w_offset >= 0,
+                   SG_ERR_INVALID_ARGUMENT, "conv2d: phase %d has a bad origin", i);
+    }
+    SG_REQUIRE(p->act == 1 || p->act == 3, SG_ERR_UNSUPPORTED, "conv2d: fused activation must be linear (1) or lrelu (3)");
+    SG_REQUIRE((int64_t)p->n * p->ci * p->h * p->w_in <= INT32_MAX && (int64_t)p->n * p->co * p->oh * p->ow <= INT32_MAX,
+               SG_ERR_INVALID_ARGUMENT, "conv2d: tensor is too large");
+    if (p->n == 0) return SG_OK;
+    SG_REQUIRE(p->x && p->w && p->y, SG_ERR_NULL_POINTER, "conv2d: x, w and y must not be NULL");
+    switch (p->dtype) {
+        case SG_F32: return launch<float>(*p, (hipStream_t)stream);
+        case SG_F16: return launch<__half>(*p, (hipStream_t)stream);
+        case SG_BF16: return launch<__hip_bfloat16>(*p, (hipStream_t)stream);
+    }
+    return fail(SG_ERR_UNSUPPORTED, "conv2d: dtype %d is not supported (f32, f16, bf16)", p->dtype);
+}

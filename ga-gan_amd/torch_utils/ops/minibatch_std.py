@@ -5,8 +5,6 @@ First-order backward is a kernel; when a higher-order graph is being recorded
 (R1 regularisation differentiates through the discriminator's backward) the
 backward re-expresses the statistic with differentiable tensor ops instead.
 """
-import ctypes
-
 import torch
 
 from ... import _lib
@@ -28,8 +26,7 @@ def _call(fn_name, x, dy, out, g, f):
     n, c, h, w = x.shape
     p = _lib.MbstdParams(x=_lib.ptr(x), dy=_lib.ptr(dy), out=_lib.ptr(out), dtype=_lib.dtype_code(x),
                          n=n, c=c, hw=h * w, g=g, f=f)
-    with torch.cuda.device(x.device):
-        _lib.check(getattr(_lib.lib(), fn_name)(ctypes.byref(p), _lib.stream_of(x)), fn_name)
+    _lib.launch(fn_name, p, x, fn_name, _lib.nbytes(x, dy, out))
 
 
 class _MinibatchStd(torch.autograd.Function):

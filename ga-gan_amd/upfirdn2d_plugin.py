@@ -2,8 +2,6 @@
 `upfirdn2d_plugin` (torch_utils/ops/upfirdn2d.cpp:16, bound at :98-101), executed by
 the gfx950 kernel behind `sg_upfirdn2d`.  Errors surface as RuntimeError, as the
 reference's TORCH_CHECKs do (upfirdn2d.cpp:19-36)."""
-import ctypes
-
 import torch
 
 from . import _lib
@@ -50,6 +48,6 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
         f_w=f.shape[1], f_h=f.shape[0], f_stride_w=f.stride(1), f_stride_h=f.stride(0),
         out_w=out_w, out_h=out_h,
         out_stride_w=y.stride(3), out_stride_h=y.stride(2), out_stride_c=y.stride(1), out_stride_n=y.stride(0))
-    with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().sg_upfirdn2d(ctypes.byref(p), _lib.stream_of(x)), 'sg_upfirdn2d')
+    label = f'upfirdn2d[up{upx}x{upy} down{downx}x{downy} f{f.shape[1]}x{f.shape[0]}]'
+    _lib.launch('sg_upfirdn2d', p, x, label, _lib.nbytes(x, y))
     return y

@@ -126,6 +126,55 @@ typedef struct sg_mbstd_params {
 int sg_mbstd_forward(const sg_mbstd_params* p, sg_stream_t stream);
 int sg_mbstd_backward(const sg_mbstd_params* p, sg_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * conv2d: implicit-GEMM convolution on the matrix cores with the StyleGAN2 layer
+ * fused around it,
+ *   y[n,co,oy,ox] = clamp(act((sum_{ci,tap} W[phase][tap][co][ci] * x[n,ci,iy,ix] * in_scale[n,ci])
+ *                             * out_scale[n,co] + noise[n,oy,ox] * *noise_gain + bias[co]) * gain)
+ * Output pixel (oy, ox) = (oy0 + a * out_step, ox0 + b * out_step) of phase `ph` reads
+ * input pixels (iy, ix) = (a * in_step + dy0 + ky, b * in_step + dx0 + kx), ky < nky, kx < nkx;
+ * reads outside the input are zero.  One phase with in_step = out_step = 1 is a plain
+ * correlation (dy0 = dx0 = -padding); in_step = 2 is a strided convolution; out_step = 2 with
+ * up to four phases is a transposed (up-sampling) convolution in polyphase form.
+ *
+ * Stands in for what the reference composes per layer from tensor ops:
+ * `modulated_conv2d` (training/networks.py:591-668: x * styles, conv2d_resample,
+ * fma with the demodulation coefficients and noise), `bias_act` after it
+ * (training/networks.py:919-921, 757-759) and the library convolution called by
+ * torch_utils/ops/conv2d_gradfix.py:43-58.  x, y: dense NCHW of `dtype` (f32, f16, bf16);
+ * w: `dtype`, packed [phase][ky][kx][co][ci] (w_offset = element offset of the phase);
+ * in_scale [n, ci], out_scale [n, co], noise [.., oh, ow] (stride noise_stride_n between
+ * samples, 0 = shared) and *noise_gain are float32; bias [co] is `dtype`.  Any of
+ * in_scale, out_scale, noise, noise_gain, bias may be NULL.  act: 1 linear, 3 lrelu(alpha).
+ */
+typedef struct sg_conv2d_phase {
+    int32_t oy0, ox0; /* first output pixel of the phase (0 .. out_step-1) */
+    int32_t dy0, dx0; /* input offset of tap (0, 0) */
+    int32_t nky, nkx; /* taps */
+    int64_t w_offset; /* element offset of this phase's [nky][nkx][co][ci] block in w */
+} sg_conv2d_phase;
+
+typedef struct sg_conv2d_params {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* in_scale;
+    const float* out_scale;
+    const void* bias;
+    const float* noise;
+    const float* noise_gain;
+    int64_t noise_stride_n;
+    int32_t dtype;
+    int32_t n, ci, h, w_in, co, oh, ow;
+    int32_t in_step, out_step;
+    int32_t num_phases;
+    sg_conv2d_phase phase[4];
+    int32_t act;
+    float alpha, gain, clamp;
+} sg_conv2d_params;
+
+int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

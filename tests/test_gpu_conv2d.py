@@ -1,0 +1,125 @@
+"""GPU parity of the matrix-core convolution kernel (sg_conv2d through its binding) against
+torch's CPU convolution in float64 on the same (rounded) inputs.  Run with -m gpu.
+
+Tolerance: float32 kernels use exact-float32 MFMA (an fma chain) -> 2e-5 of the output's max
+magnitude; bf16 / fp16 kernels multiply 16-bit operands exactly, accumulate in float32 and round
+once on store -> one unit in the last place of the storage type (2^-8 / 2^-11), doubled when the
+scaled input is rounded to the storage type before the multiply (in_scale)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+ULP = {torch.float32: 2e-5, torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10}
+
+
+def close(a, b, tol, what=''):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-3)
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, (what, err, scale)
+
+
+CASES = [  # name, n, ci, co, h, w, k, kind, stride, padding
+    ('3x3_same', 3, 32, 64, 16, 16, 3, 'conv', 1, 1),
+    ('3x3_big', 2, 64, 64, 64, 64, 3, 'conv', 1, 1),
+    ('3x3_ragged', 3, 40, 72, 19, 23, 3, 'conv', 1, 1),
+    ('3x3_lowres', 5, 64, 128, 4, 4, 3, 'conv', 1, 1),
+    ('3x3_8x8', 9, 32, 64, 8, 8, 3, 'conv', 1, 1),
+    ('1x1_torgb', 3, 64, 3, 32, 32, 1, 'conv', 1, 0),
+    ('1x1_fromrgb', 3, 3, 64, 32, 32, 1, 'conv', 1, 0),
+    ('1x1_skip', 2, 64, 128, 16, 16, 1, 'conv', 1, 0),
+    ('3x3_stride2', 2, 32, 64, 33, 33, 3, 'conv', 2, 0),
+    ('3x3_stride2_ragged', 2, 24, 48, 21, 27, 3, 'conv', 2, 0),
+    ('3x3_nopad', 2, 32, 32, 18, 18, 3, 'conv', 1, 0),
+    ('t3x3_up2', 2, 64, 32, 16, 16, 3, 'conv_transpose', 2, 0),
+    ('t3x3_up2_pad1', 2, 32, 32, 9, 13, 3, 'conv_transpose', 2, 1),
+    ('t3x3_lowres', 4, 64, 64, 4, 4, 3, 'conv_transpose', 2, 0),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_conv2d_plain(case, dtype):
+    from ga_gan_amd import conv2d_plugin as cp
+    name, n, ci, co, h, w, k, kind, stride, padding = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn([n, ci, h, w], generator=g).to(dtype)
+    if kind == 'conv':
+        wt = (torch.randn([co, ci, k, k], generator=g) / (ci * k * k) ** 0.5).to(dtype)
+        want = F.conv2d(x.double(), wt.double(), stride=stride, padding=padding)
+        plan = cp.plan_conv(k, k, stride=stride, padding=padding)
+        packed = plan.pack(wt.to(DEV))
+    else:
+        wt = (torch.randn([ci, co, k, k], generator=g) / (ci * k * k) ** 0.5).to(dtype)
+        want = F.conv_transpose2d(x.double(), wt.double(), stride=stride, padding=padding)
+        plan = cp.plan_conv_transpose(k, k, stride=stride, padding=padding)
+        packed = plan.pack(wt.to(DEV), transposed_layout=True)
+    y = cp.conv2d(x.to(DEV), packed, plan, co)
+    assert y.dtype == dtype
+    close(y, want, ULP[dtype], name)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('up', [1, 2])
+def test_conv2d_fused_layer(dtype, up):
+    """Modulation, demodulation, noise, bias, leaky ReLU, gain and clamp around the contraction."""
+    from ga_gan_amd import conv2d_plugin as cp
+    g = torch.Generator().manual_seed(11 + up)
+    n, ci, co, h = 4, 64, 48, 16
+    x = torch.randn([n, ci, h, h], generator=g).to(dtype)
+    s = torch.randn([n, ci], generator=g) * 0.5 + 1
+    d = torch.rand([n, co], generator=g) + 0.5
+    b = torch.randn([co], generator=g).to(dtype)
+    ng = torch.tensor(0.7)
+    if up == 1:
+        wt = (torch.randn([co, ci, 3, 3], generator=g) / 24).to(dtype)
+        plan = cp.plan_conv(3, 3, padding=1)
+        packed = plan.pack(wt.to(DEV))
+        conv = lambda t: F.conv2d(t, wt.double(), padding=1)
+    else:
+        wt = (torch.randn([ci, co, 3, 3], generator=g) / 24).to(dtype)
+        plan = cp.plan_conv_transpose(3, 3, stride=2)
+        packed = plan.pack(wt.to(DEV), transposed_layout=True)
+        conv = lambda t: F.conv_transpose2d(t, wt.double(), stride=2)
+    oh = plan.out_size(h, h)[0]
+    for noise in (torch.randn([oh, oh], generator=g), torch.randn([n, 1, oh, oh], generator=g)):
+        xs = (x.float() * s.reshape(n, ci, 1, 1)).to(dtype)        # the kernel rounds the scaled input to dtype
+        pre = conv(xs.double()) * d.double().reshape(n, co, 1, 1) + noise.double() * 0.7 + b.double().reshape(1, co, 1, 1)
+        want = (F.leaky_relu(pre, 0.2) * 1.4142).clamp(-2.0, 2.0)
+        y = cp.conv2d(x.to(DEV), packed, plan, co, in_scale=s.to(DEV), out_scale=d.to(DEV), bias=b.to(DEV),
+                      noise=noise.to(DEV).contiguous(), noise_gain=ng.to(DEV), act='lrelu', alpha=0.2, gain=1.4142, clamp=2.0)
+        close(y, want, 2 * ULP[dtype], f'up{up} noise{tuple(noise.shape)}')
+
+
+def test_conv2d_bench_shapes_match_library_conv():
+    """Bench-size layers (256-config, batch 8) against the library convolution on the GPU in float32."""
+    from ga_gan_amd import conv2d_plugin as cp
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for ci, co, h in ((64, 64, 256), (128, 128, 128), (512, 512, 32)):
+        x = torch.randn([8, ci, h, h], device=DEV, generator=g).to(torch.bfloat16)
+        wt = (torch.randn([co, ci, 3, 3], device=DEV, generator=g) / (ci * 9) ** 0.5).to(torch.bfloat16)
+        plan = cp.plan_conv(3, 3, padding=1)
+        y = cp.conv2d(x, plan.pack(wt), plan, co)
+        want = F.conv2d(x.float(), wt.float(), padding=1)
+        close(y, want, 2 ** -7, f'{ci}->{co}@{h}')
+
+
+def test_conv2d_errors():
+    from ga_gan_amd import conv2d_plugin as cp
+    plan = cp.plan_conv(3, 3, padding=1)
+    x = torch.zeros([1, 8, 8, 8], device=DEV)
+    w = plan.pack(torch.zeros([8, 8, 3, 3], device=DEV))
+    with pytest.raises(RuntimeError, match='CUDA'):
+        cp.conv2d(x.cpu(), w, plan, 8)
+    with pytest.raises(RuntimeError, match='dtype'):
+        cp.conv2d(x, w.half(), plan, 8)
+    with pytest.raises(RuntimeError, match='elements'):
+        cp.conv2d(x, w[:-1].contiguous(), plan, 8)
+    with pytest.raises(RuntimeError, match='in_scale'):
+        cp.conv2d(x, w, plan, 8, in_scale=torch.zeros([1, 4], device=DEV))
+    with pytest.raises(RuntimeError, match='not supported|dtype'):
+        cp.conv2d(x.double(), w.double(), plan, 8)
+    assert cp.conv2d(x[:0], w, plan, 8).shape == (0, 8, 8, 8)
