@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsgops.so')
 
 SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
-           'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d')
+           'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -64,8 +64,9 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = [ctypes.POINTER(struct), vp]
             fn.restype = ctypes.c_int
-        handle.sg_conv2d.argtypes = [vp, vp]      # struct declared in conv2d_plugin.py
-        handle.sg_conv2d.restype = ctypes.c_int
+        for name in ('sg_conv2d', 'sg_conv2d_wgrad'):     # structs declared in conv2d_plugin.py
+            getattr(handle, name).argtypes = [vp, vp]
+            getattr(handle, name).restype = ctypes.c_int
         _lib = handle
     return _lib
 

@@ -85,8 +85,9 @@ ACT_INDEX = {'linear': 1, 'lrelu': 3}
 
 
 def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
-           act='linear', alpha=0.2, gain=1.0, clamp=-1.0):
-    """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow]."""
+           act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None):
+    """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow].
+    `out_hw` overrides the plan's natural output size (pixels whose taps all fall outside x are zero)."""
     if not x.is_cuda:
         raise RuntimeError('x must reside on CUDA device')
     if x.dim() != 4 or not x.is_contiguous():
@@ -94,7 +95,7 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     if w_packed.dtype != x.dtype or w_packed.device != x.device or not w_packed.is_contiguous():
         raise RuntimeError('packed weights must be dense and have the dtype and device of x')
     n, ci, h, w = x.shape
-    oh, ow = plan.out_size(h, w)
+    oh, ow = plan.out_size(h, w) if out_hw is None else out_hw
     if oh < 1 or ow < 1:
         raise RuntimeError('output must be at least 1x1')
     expect = sum(ph[4] * ph[5] for ph in plan.phases) * co * ci
@@ -131,3 +132,37 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     label = f'conv2d[{plan.kind} {plan.kh}x{plan.kw} in{plan.in_step} out{plan.out_step} {ci}->{co} @{oh}]'
     _lib.launch('sg_conv2d', p, x, label, _lib.nbytes(x, y), flops=2.0 * n * co * ci * taps * (oh * ow) / len(plan.phases))
     return y
+
+
+class Conv2dWgradParams(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('g', ctypes.c_void_p), ('dw', ctypes.c_void_p),
+                ('x_scale', ctypes.c_void_p), ('g_scale', ctypes.c_void_p), ('dtype', ctypes.c_int32),
+                ('n', ctypes.c_int32), ('cx', ctypes.c_int32), ('h', ctypes.c_int32), ('w_in', ctypes.c_int32),
+                ('cg', ctypes.c_int32), ('gh', ctypes.c_int32), ('gw', ctypes.c_int32),
+                ('step', ctypes.c_int32), ('dy0', ctypes.c_int32), ('dx0', ctypes.c_int32),
+                ('nky', ctypes.c_int32), ('nkx', ctypes.c_int32)]
+
+
+def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None):
+    """dw[cg, cx, kh, kw] (float32) = sum_{n,a,b} g[n,cg,a,b] * x[n,cx,a*stride+ky-padding,b*stride+kx-padding],
+    with optional per-sample channel scales on both operands.  For y = conv2d(x, w, stride, padding) pass
+    g = dy; for y = conv_transpose2d(x, w[ci, co]) pass (x=dy, g=x), which yields dw in w's [ci, co] layout."""
+    if not (x.is_cuda and g.is_cuda):
+        raise RuntimeError('x and g must reside on CUDA device')
+    if x.dim() != 4 or g.dim() != 4 or not x.is_contiguous() or not g.is_contiguous():
+        raise RuntimeError('x and g must be dense NCHW tensors of rank 4')
+    if x.dtype != g.dtype or x.shape[0] != g.shape[0]:
+        raise RuntimeError('x and g must agree in dtype and batch size')
+    n, cx, h, w = x.shape
+    _, cg, gh, gw = g.shape
+    for name, t, shape in (('x_scale', x_scale, (n, cx)), ('g_scale', g_scale, (n, cg))):
+        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous()):
+            raise RuntimeError(f'{name} must be a dense float32 tensor of shape {shape}')
+    dw = torch.zeros([kh, kw, cg, cx], dtype=torch.float32, device=x.device)
+    if n > 0:
+        p = Conv2dWgradParams(x=_lib.ptr(x), g=_lib.ptr(g), dw=_lib.ptr(dw), x_scale=_lib.ptr(x_scale),
+                              g_scale=_lib.ptr(g_scale), dtype=_lib.dtype_code(x), n=n, cx=cx, h=h, w_in=w, cg=cg,
+                              gh=gh, gw=gw, step=stride, dy0=-padding, dx0=-padding, nky=kh, nkx=kw)
+        label = f'conv2d_wgrad[{kh}x{kw} step{stride} {cx}x{cg} @{gh}]'
+        _lib.launch('sg_conv2d_wgrad', p, x, label, _lib.nbytes(x, g), flops=2.0 * n * cg * cx * kh * kw * gh * gw)
+    return dw.permute(2, 3, 0, 1)

@@ -64,6 +64,62 @@ struct Tile {
     int tiles_a, tiles_b, tiles_img;
 };
 
+
+// Copy the footprint [imgs][lh][lw] (top-left input pixel (iy0, ix0), images img0..) of channels
+// c0 .. c0 + chunk of a dense NCHW tensor into LDS as [pixel][channel], multiplied by
+// scale[n, c] when given.  Pixels outside the tensor are zero.  A lane owns pixels (coalesced
+// along x) and walks the chunk's channels: the coordinates are decoded once, a channel step is
+// one pointer increment.
+template <class T>
+__device__ __forceinline__ void stage_pixels(unsigned char* s_dst, const T* __restrict__ x, const float* __restrict__ scale,
+                                             int n_total, int c_total, int h, int w, int c0, int img0, int imgs, int iy0,
+                                             int ix0, int lh, int lw) {
+    constexpr int KCH = kChunkBytes / (int)sizeof(T);
+    const int64_t plane = (int64_t)h * w;
+    const int pixels = imgs * lh * lw;
+    for (int pix = threadIdx.x; pix < pixels; pix += kThreads) {
+        const int rx = pix % lw;
+        const int ry = (pix / lw) % lh;
+        const int ri = pix / (lw * lh);
+        const int iy = iy0 + ry, ix = ix0 + rx, n = img0 + ri;
+        const bool inside = iy >= 0 && iy < h && ix >= 0 && ix < w && n < n_total;
+        unsigned char* dst = s_dst + pix * kPitch;
+        if (!inside) {
+#pragma unroll
+            for (int q = 0; q < kChunkBytes / 16; q++) *reinterpret_cast<uint4*>(dst + q * 16) = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        const T* src = x + ((int64_t)n * c_total + c0) * plane + (int64_t)iy * w + ix;
+        const float* sc = scale ? scale + (int64_t)n * c_total + c0 : nullptr;
+        const int left = c_total - c0;   // channels that exist from c0 on
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll 4
+            for (int cp = 0; cp < KCH / 2; cp++) {
+                const int c = 2 * cp;
+                T h0 = Elem<T>::store(0), h1 = Elem<T>::store(0);
+                if (c < left) h0 = src[(int64_t)c * plane];
+                if (c + 1 < left) h1 = src[(int64_t)(c + 1) * plane];
+                if (sc) {
+                    if (c < left) h0 = Elem<T>::store(Elem<T>::load(h0) * sc[c]);
+                    if (c + 1 < left) h1 = Elem<T>::store(Elem<T>::load(h1) * sc[c + 1]);
+                }
+                *reinterpret_cast<unsigned*>(dst + cp * 4) =
+                    (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            }
+        } else {
+#pragma unroll 4
+            for (int c = 0; c < KCH; c++) {
+                float v = 0;
+                if (c < left) {
+                    v = Elem<T>::load(src[(int64_t)c * plane]);
+                    if (sc) v *= sc[c];
+                }
+                *reinterpret_cast<float*>(dst + c * 4) = v;
+            }
+        }
+    }
+}
+
 template <class T, int M_TILES>
 __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_params p, Tile t) {
     using S = float;
@@ -89,7 +145,6 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     const int taps = ph.nky * ph.nkx;
     const int lw = (t.tw - 1) * p.in_step + ph.nkx;
     const int lh = (t.th - 1) * p.in_step + ph.nky;
-    const int in_pixels = t.imgs * lh * lw;
     const int iy0 = a0 * p.in_step + ph.dy0, ix0 = b0 * p.in_step + ph.dx0;
 
     unsigned char* s_in = smem;
@@ -117,54 +172,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const bool w_vec = (p.ci % (16 / (int)sizeof(T)) == 0);
-    const int64_t plane = (int64_t)p.h * p.w_in;
-
     for (int c0 = 0; c0 < p.ci; c0 += KCH) {
         __syncthreads();   // everyone is done reading the previous chunk
-        // ---- stage the input footprint: [pixel][channel], scaled ------------------------------
-        // A lane owns pixels (coalesced along x) and walks the chunk's channels; the pixel's
-        // coordinates are decoded once per chunk, a channel step is one pointer increment.
-        for (int pix = tid; pix < in_pixels; pix += kThreads) {
-            const int rx = pix % lw;
-            const int ry = (pix / lw) % lh;
-            const int ri = pix / (lw * lh);
-            const int iy = iy0 + ry, ix = ix0 + rx, n = img0 + ri;
-            const bool inside = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w_in && n < p.n;
-            unsigned char* dst = s_in + pix * kPitch;
-            if (!inside) {
-#pragma unroll
-                for (int q = 0; q < kChunkBytes / 16; q++) *reinterpret_cast<uint4*>(dst + q * 16) = make_uint4(0, 0, 0, 0);
-                continue;
-            }
-            const T* src = x + ((int64_t)n * p.ci + c0) * plane + (int64_t)iy * p.w_in + ix;
-            const float* sc = p.in_scale ? p.in_scale + (int64_t)n * p.ci + c0 : nullptr;
-            const int left = p.ci - c0;   // channels that exist from c0 on
-            if constexpr (sizeof(T) == 2) {
-#pragma unroll 4
-                for (int cp = 0; cp < KCH / 2; cp++) {
-                    const int c = 2 * cp;
-                    T h0 = Elem<T>::store(0), h1 = Elem<T>::store(0);
-                    if (c < left) h0 = src[(int64_t)c * plane];
-                    if (c + 1 < left) h1 = src[(int64_t)(c + 1) * plane];
-                    if (sc) {
-                        if (c < left) h0 = Elem<T>::store(Elem<T>::load(h0) * sc[c]);
-                        if (c + 1 < left) h1 = Elem<T>::store(Elem<T>::load(h1) * sc[c + 1]);
-                    }
-                    *reinterpret_cast<unsigned*>(dst + cp * 4) =
-                        (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                }
-            } else {
-#pragma unroll 4
-                for (int c = 0; c < KCH; c++) {
-                    S v = 0;
-                    if (c < left) {
-                        v = Elem<T>::load(src[(int64_t)c * plane]);
-                        if (sc) v *= sc[c];
-                    }
-                    *reinterpret_cast<float*>(dst + c * 4) = v;
-                }
-            }
-        }
+        stage_pixels<T>(s_in, x, p.in_scale, p.n, p.ci, p.h, p.w_in, c0, img0, t.imgs, iy0, ix0, lh, lw);
         // ---- stage the weight chunk: [tap][BM][channel] ----------------------------------------
         if (w_vec) {
             for (int e = tid; e < taps * BM * 4; e += kThreads) {
@@ -289,6 +299,174 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     return check_launch("sg_conv2d");
 }
 
+
+// ---------------------------------------------------------------------------
+// Weight gradient:  dw[ky][kx][cg][cx] += sum_{n,a,b} g[n,cg,a,b] * g_scale[n,cg]
+//                                          * x[n,cx,a*step+dy0+ky,b*step+dx0+kx] * x_scale[n,cx]
+// GEMM view per tap: M = cg, N = cx, K = pixels.  Both operands are staged exactly like the
+// forward kernel's input, [pixel][channel], so K (pixels) runs down the LDS rows; the
+// 16-bit path fetches its fragments with the transposing LDS read (4 pixel rows x 16 channel
+// columns per 16 lanes, a lane receives 4 consecutive pixels of one channel), which also
+// makes the per-tap pixel shift free.  A workgroup owns one (cg chunk, cx chunk) pair and
+// strides over pixel tiles (split K); every wave reduces 64 pixels per tile into taps x
+// (chunk/16)^2 accumulator tiles and adds them to dw with float atomics at the end.
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
+
+template <class T> struct WgradFrag;      // fragment fetch + MFMA for one 16-channel tile pair
+template <class T16> struct WgradFrag16 {
+    // pixel k-step of 32: lane group g takes pixels 8g..8g+7, two transposing reads of 4 pixels
+    static constexpr int kPixelsPerStep = 32;
+    static __device__ __forceinline__ uint4 fetch(const unsigned char* base, const int (&pix_off)[2], int chan_byte) {
+        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(base + pix_off[0] + chan_byte));
+        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(base + pix_off[1] + chan_byte));
+        uint4 r;
+        r.x = __builtin_bit_cast(uint2, lo).x; r.y = __builtin_bit_cast(uint2, lo).y;
+        r.z = __builtin_bit_cast(uint2, hi).x; r.w = __builtin_bit_cast(uint2, hi).y;
+        return r;
+    }
+};
+
+template <class T, int MAX_TAPS>
+__global__ void __launch_bounds__(kThreads) conv2d_wgrad_kernel(sg_conv2d_wgrad_params p, Tile t, int tiles_total) {
+    constexpr int KCH = kChunkBytes / (int)sizeof(T);   // channels per chunk: 32 (16-bit) or 16 (f32)
+    constexpr int NT = KCH / 16;                        // 16-channel tiles per chunk
+    constexpr bool HALF = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int cg0 = blockIdx.y * KCH, cx0 = blockIdx.z * KCH;
+    const int taps = p.nky * p.nkx;
+    const int lw = (t.tw - 1) * p.step + p.nkx, lh = (t.th - 1) * p.step + p.nky;
+    unsigned char* s_x = smem;
+    unsigned char* s_g = smem + (size_t)t.imgs * lh * lw * kPitch;
+    const T* __restrict__ x = (const T*)p.x;
+    const T* __restrict__ g = (const T*)p.g;
+
+    f32x4_t acc[MAX_TAPS][NT][NT];
+#pragma unroll
+    for (int tp = 0; tp < MAX_TAPS; tp++)
+#pragma unroll
+        for (int m = 0; m < NT; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[tp][m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // LDS byte offsets (without the tap shift) of the pixels this lane addresses, per k-step.
+    //  16-bit: 2 k-steps x 2 reads; lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3.
+    //  f32   : 16 k-steps; lane group g addresses pixel 4*kstep + g, channel lrow.
+    constexpr int KSTEPS = HALF ? 2 : 16;
+    int gx_off[KSTEPS][2], gg_off[KSTEPS][2];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const int slot = HALF ? (wave * 64 + ks * 32 + lgrp * 8 + hf * 4 + (lrow >> 2)) : (wave * 64 + ks * 4 + lgrp);
+            const int rb = slot & (t.tw - 1);
+            const int ra = (slot >> t.tw_shift) & (t.th - 1);
+            const int ri = slot >> (t.tw_shift + t.th_shift);
+            const int chan = HALF ? (lrow & 3) * 8 : lrow * 4;
+            gx_off[ks][hf] = ((ri * lh + ra * p.step) * lw + rb * p.step) * kPitch + chan;
+            gg_off[ks][hf] = slot * kPitch + chan;
+        }
+
+    for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+        int rest = tile;
+        const int tb = rest % t.tiles_b; rest /= t.tiles_b;
+        const int ta = rest % t.tiles_a; rest /= t.tiles_a;
+        const int img0 = rest * t.imgs;
+        const int a0 = ta * t.th, b0 = tb * t.tw;
+        __syncthreads();
+        stage_pixels<T>(s_x, x, p.x_scale, p.n, p.cx, p.h, p.w_in, cx0, img0, t.imgs, a0 * p.step + p.dy0,
+                        b0 * p.step + p.dx0, lh, lw);
+        stage_pixels<T>(s_g, g, p.g_scale, p.n, p.cg, p.gh, p.gw, cg0, img0, t.imgs, a0, b0, t.th, t.tw);
+        __syncthreads();
+
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            uint4 a[NT];
+#pragma unroll
+            for (int m = 0; m < NT; m++) {
+                if constexpr (HALF) a[m] = WgradFrag16<T>::fetch(s_g, gg_off[ks], m * 32);
+                else a[m].x = *reinterpret_cast<const unsigned*>(s_g + gg_off[ks][0]);
+            }
+#pragma unroll
+            for (int tp = 0; tp < MAX_TAPS; tp++) {
+                if (tp < taps) {
+                    const int ky = tp / p.nkx, kx = tp - ky * p.nkx;
+                    const unsigned char* sx = s_x + (ky * lw + kx) * kPitch;
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        uint4 b;
+                        if constexpr (HALF) b = WgradFrag16<T>::fetch(sx, gx_off[ks], n * 32);
+                        else b.x = *reinterpret_cast<const unsigned*>(sx + gx_off[ks][0]);
+#pragma unroll
+                        for (int m = 0; m < NT; m++) {
+                            if constexpr (HALF) Mma<T>::run(a[m], b, acc[tp][m][n]);
+                            else acc[tp][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[m].x),
+                                                                                       __builtin_bit_cast(float, b.x), acc[tp][m][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- reduce into dw[tap][cg][cx] --------------------------------------------------------------
+    float* __restrict__ dw = p.dw;
+#pragma unroll
+    for (int tp = 0; tp < MAX_TAPS; tp++) {
+        if (tp < taps) {
+#pragma unroll
+            for (int m = 0; m < NT; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int cg = cg0 + m * 16 + lgrp * 4 + r, cx = cx0 + n * 16 + lrow;
+                        if (cg < p.cg && cx < p.cx) atomicAdd(dw + ((int64_t)tp * p.cg + cg) * p.cx + cx, acc[tp][m][n][r]);
+                    }
+        }
+    }
+}
+
+template <class T>
+int launch_wgrad(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
+    Tile t;
+    t.tw = 32;
+    while (t.tw > 4 && t.tw / 2 >= p.gw) t.tw /= 2;
+    int rest = kPixels / t.tw;
+    t.th = (p.step == 1) ? 8 : 4;
+    if (t.th > rest) t.th = rest;
+    while (t.th > 1 && t.th / 2 >= p.gh) t.th /= 2;
+    t.imgs = rest / t.th;
+    t.tw_shift = ilog2(t.tw);
+    t.th_shift = ilog2(t.th);
+    t.lw = (t.tw - 1) * p.step + p.nkx;
+    t.lh = (t.th - 1) * p.step + p.nky;
+    t.tiles_b = (p.gw + t.tw - 1) / t.tw;
+    t.tiles_a = (p.gh + t.th - 1) / t.th;
+    t.tiles_img = (p.n + t.imgs - 1) / t.imgs;
+    const int64_t tiles = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img;
+    SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: too many tiles");
+    constexpr int KCH = kChunkBytes / (int)sizeof(T);
+    const int chunks_g = (p.cg + KCH - 1) / KCH, chunks_x = (p.cx + KCH - 1) / KCH;
+    // split K so that about four workgroups per CU exist; every split ends in taps*KCH*KCH atomics
+    int64_t split = (1024 + (int64_t)chunks_g * chunks_x - 1) / ((int64_t)chunks_g * chunks_x);
+    if (split > tiles) split = tiles;
+    if (split < 1) split = 1;
+    const size_t lds = ((size_t)t.imgs * t.lh * t.lw + kPixels) * kPitch;
+    SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d_wgrad: tile needs %zu bytes of LDS", lds);
+    const int taps = p.nky * p.nkx;
+    dim3 grid((unsigned)split, (unsigned)chunks_g, (unsigned)chunks_x);
+    auto kernel = (taps <= 1) ? conv2d_wgrad_kernel<T, 1> : (taps <= 4) ? conv2d_wgrad_kernel<T, 4> : conv2d_wgrad_kernel<T, 9>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail((int)e, "conv2d_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, p, t, (int)tiles);
+    return check_launch("sg_conv2d_wgrad");
+}
+
 }  // namespace
 }  // namespace sg
 
@@ -318,4 +496,24 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
         case SG_BF16: return launch<__hip_bfloat16>(*p, (hipStream_t)stream);
     }
     return fail(SG_ERR_UNSUPPORTED, "conv2d: dtype %d is not supported (f32, f16, bf16)", p->dtype);
+}
+
+extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stream) {
+    using namespace sg;
+    SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
+    SG_REQUIRE(p->n >= 0 && p->cx >= 1 && p->cg >= 1 && p->h >= 1 && p->w_in >= 1 && p->gh >= 1 && p->gw >= 1,
+               SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: bad tensor sizes");
+    SG_REQUIRE(p->step >= 1 && p->step <= 2, SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: step must be 1 or 2");
+    SG_REQUIRE(p->nky >= 1 && p->nkx >= 1 && p->nky * p->nkx <= 9, SG_ERR_INVALID_ARGUMENT,
+               "conv2d_wgrad: %dx%d taps (at most 9 in total)", p->nky, p->nkx);
+    SG_REQUIRE((int64_t)p->n * p->cx * p->h * p->w_in <= INT32_MAX && (int64_t)p->n * p->cg * p->gh * p->gw <= INT32_MAX,
+               SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: tensor is too large");
+    if (p->n == 0) return SG_OK;
+    SG_REQUIRE(p->x && p->g && p->dw, SG_ERR_NULL_POINTER, "conv2d_wgrad: x, g and dw must not be NULL");
+    switch (p->dtype) {
+        case SG_F32: return launch_wgrad<float>(*p, (hipStream_t)stream);
+        case SG_F16: return launch_wgrad<__half>(*p, (hipStream_t)stream);
+        case SG_BF16: return launch_wgrad<__hip_bfloat16>(*p, (hipStream_t)stream);
+    }
+    return fail(SG_ERR_UNSUPPORTED, "conv2d_wgrad: dtype %d is not supported (f32, f16, bf16)", p->dtype);
 }

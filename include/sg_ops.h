@@ -175,6 +175,32 @@ typedef struct sg_conv2d_params {
 
 int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * conv2d_wgrad: weight gradient of the convolution above (one phase),
+ *   dw[ky][kx][cg][cx] += sum_{n,a,b} g[n,cg,a,b] * g_scale[n,cg]
+ *                                     * x[n,cx,a*step+dy0+ky,b*step+dx0+kx] * x_scale[n,cx]
+ * x [n, cx, h, w_in] and g [n, cg, gh, gw] are dense NCHW of `dtype`; dw is float32,
+ * packed [nky][nkx][cg][cx], and is ACCUMULATED into with float atomics (the caller
+ * zeroes it).  For a forward y = conv(x, W) pass g = dy (cg = co, cx = ci); for a
+ * transposed convolution exchange the roles of x and dy.  x_scale [n, cx] and
+ * g_scale [n, cg] (float32) may be NULL.
+ *
+ * Stands in for the library weight-gradient call of
+ * torch_utils/ops/conv2d_gradfix.py:175-191 (`cudnn_convolution_backward_weight`).
+ */
+typedef struct sg_conv2d_wgrad_params {
+    const void* x;
+    const void* g;
+    float* dw;
+    const float* x_scale;
+    const float* g_scale;
+    int32_t dtype;
+    int32_t n, cx, h, w_in, cg, gh, gw;
+    int32_t step, dy0, dx0, nky, nkx;
+} sg_conv2d_wgrad_params;
+
+int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,52 @@ def test_conv2d_errors():
     with pytest.raises(RuntimeError, match='not supported|dtype'):
         cp.conv2d(x.double(), w.double(), plan, 8)
     assert cp.conv2d(x[:0], w, plan, 8).shape == (0, 8, 8, 8)
+
+
+WGRAD_CASES = [  # name, n, ci, co, h, w, k, stride, padding
+    ('3x3_same', 3, 32, 64, 16, 16, 3, 1, 1),
+    ('3x3_big', 4, 64, 64, 64, 64, 3, 1, 1),
+    ('3x3_ragged', 3, 40, 72, 19, 23, 3, 1, 1),
+    ('3x3_lowres', 8, 64, 96, 4, 4, 3, 1, 1),
+    ('1x1', 3, 64, 3, 32, 32, 1, 1, 0),
+    ('1x1_fromrgb', 3, 3, 64, 32, 32, 1, 1, 0),
+    ('3x3_stride2', 2, 32, 64, 33, 33, 3, 2, 0),
+    ('3x3_nopad', 2, 32, 32, 18, 18, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_conv2d_wgrad(case, dtype):
+    from ga_gan_amd import conv2d_plugin as cp
+    name, n, ci, co, h, w, k, stride, padding = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn([n, ci, h, w], generator=g).to(dtype)
+    wt = torch.zeros([co, ci, k, k], dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), wt, stride=stride, padding=padding)
+    dy = torch.randn(y.shape, generator=g).to(dtype)
+    want, = torch.autograd.grad(y, wt, dy.double())
+    xs, gs = torch.rand([n, ci], generator=g) + 0.5, torch.rand([n, co], generator=g) + 0.5
+    dw = cp.conv2d_wgrad(x.to(DEV), dy.to(DEV), k, k, stride=stride, padding=padding)
+    assert dw.dtype == torch.float32 and dw.shape == wt.shape
+    # products of 16-bit operands are exact, sums are float32: only summation-order error is left
+    close(dw, want, 2e-5 if dtype == torch.float32 else 1e-4, name)
+    # with per-sample scales (operands are rounded to dtype after scaling)
+    x2 = (x.float() * xs.reshape(n, ci, 1, 1)).to(dtype)
+    dy2 = (dy.float() * gs.reshape(n, co, 1, 1)).to(dtype)
+    want2, = torch.autograd.grad(F.conv2d(x2.double(), wt, stride=stride, padding=padding), wt, dy2.double())
+    dw2 = cp.conv2d_wgrad(x.to(DEV), dy.to(DEV), k, k, stride=stride, padding=padding, x_scale=xs.to(DEV), g_scale=gs.to(DEV))
+    close(dw2, want2, 2e-5 if dtype == torch.float32 else 1e-4, name + ' scaled')
+
+
+def test_conv2d_wgrad_transposed_roles():
+    """Weight gradient of a transposed convolution = the same kernel with x and dy exchanged."""
+    from ga_gan_amd import conv2d_plugin as cp
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn([2, 32, 9, 9], generator=g).to(torch.bfloat16)
+    wt = torch.zeros([32, 48, 3, 3], dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(x.double(), wt, stride=2)
+    dy = torch.randn(y.shape, generator=g).to(torch.bfloat16)
+    want, = torch.autograd.grad(y, wt, dy.double())
+    dw = cp.conv2d_wgrad(dy.to(DEV), x.to(DEV), 3, 3, stride=2, padding=0)
+    close(dw, want, 1e-4)
