@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'float': 157.3}   # dense matrix-core peaks
 
 CONFIGS = {
     # name: (description, cfg preset, resolution, per-GPU batch, parameterisation)
@@ -55,9 +56,11 @@ def make_trainer(args, rank, world):
 
 
 def kernel_roofline(trainer, real, real_c, steps):
-    """Instrumented pass: HIP events around every launch of the hand-written kernels (on the stream
-    they are launched on), grouped by kernel; the kernel with the largest total time is reported
-    with its algorithmic bytes (operands read once + result written once) per launch."""
+    """Instrumented pass: HIP events around every launch of the hand-written kernels (recorded on the
+    stream they are launched on), grouped by kernel symbol.  The kernel with the largest total time is the
+    dominant one: for the matrix-core convolutions it is priced against the dense MFMA peak of its dtype
+    (algorithmic flops per launch / average launch time), for the streaming kernels against HBM
+    (algorithmic bytes per launch = operands read once + result written once)."""
     from ga_gan_amd import _lib
     _lib.profile_begin()
     for _ in range(steps):
@@ -66,19 +69,30 @@ def kernel_roofline(trainer, real, real_c, steps):
     if not records:
         return None, {}
     by_kernel = {}
-    for name, nbytes, ms, _flops in records:
-        k = by_kernel.setdefault(name, dict(launches=0, bytes=0, ms=0.0))
+    for name, nbytes, ms, flops in records:
+        k = by_kernel.setdefault(name, dict(launches=0, bytes=0, ms=0.0, flops=0.0))
         k['launches'] += 1
         k['bytes'] += nbytes
         k['ms'] += ms
+        k['flops'] += flops
     name, k = max(by_kernel.items(), key=lambda kv: kv[1]['ms'])
     avg_ms = k['ms'] / k['launches']
-    achieved = (k['bytes'] / k['launches']) / (avg_ms * 1e-3) / 1e9
-    roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None, launches=k['launches'],
-                    avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
-    summary = {n: dict(launches=v['launches'], total_ms=round(v['ms'], 3),
-                       gbps=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)) for n, v in by_kernel.items()}
+    if k['flops'] > 0:
+        peak = MFMA_PEAK_TFLOPS['float' if '<float' in name else 'bf16']
+        achieved = (k['flops'] / k['launches']) / (avg_ms * 1e-3) / 1e12
+        roofline = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
+                        frac=round(achieved / peak, 4), traffic=None, launches=k['launches'],
+                        avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_flops_per_launch=int(k['flops'] / k['launches']),
+                        algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
+    else:
+        achieved = (k['bytes'] / k['launches']) / (avg_ms * 1e-3) / 1e9
+        roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None, launches=k['launches'],
+                        avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
+    summary = {n: dict(launches_per_step=v['launches'] // steps, ms_per_step=round(v['ms'] / steps, 3),
+                       gbps=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1),
+                       tflops=round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 2))
+               for n, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]['ms'])}
     return roofline, summary
 
 
@@ -193,7 +207,7 @@ def main():
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
                    config=dict(workload=desc, resolution=res, global_batch=global_batch, per_gpu_batch=batch_gpu,
                                parallelism=f'dp{world}', iteration='Gmain+Dmain every step, Greg every 4th, Dreg every 16th',
-                               conv_backend='MIOpen via torch (3x3/1x1 contractions); upfirdn2d, bias_act, minibatch-std: HIP'),
+                               kernels='conv2d / conv2d_wgrad (MFMA), upfirdn2d, bias_act, minibatch-std: hand-written HIP; small GEMMs: torch'),
                    roofline=roofline, cpu_baseline=baseline, kernels=kernels,
                    grad_exchange_bytes_per_step=int(trainer.exchanged_bytes / max(trainer.batch_idx, 1)))
         print(json.dumps(out), flush=True)

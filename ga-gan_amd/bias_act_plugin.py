@@ -55,5 +55,5 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
         x=_lib.ptr(x), b=_lib.ptr(b), xref=_lib.ptr(xref), yref=_lib.ptr(yref), dy=_lib.ptr(dy), y=_lib.ptr(y),
         dtype=_lib.dtype_code(x), grad=grad, act=act, alpha=alpha, gain=gain, clamp=clamp,
         size_x=x.numel(), size_b=b.numel(), step_b=x.stride(dim) if b.numel() else 1)
-    _lib.launch('sg_bias_act', p, x, f'bias_act[act{act} grad{grad}]', _lib.nbytes(x, xref, yref, dy, y))
+    _lib.launch('sg_bias_act', p, x, f'bias_act_kernel<act{act}>', _lib.nbytes(x, xref, yref, dy, y))
     return y

@@ -82,6 +82,7 @@ def plan_conv_transpose(kh, kw, stride=2, padding=0):
 
 
 ACT_INDEX = {'linear': 1, 'lrelu': 3}
+_DTYPE_NAME = {torch.float32: 'float', torch.float16: '__half', torch.bfloat16: '__hip_bfloat16'}
 
 
 def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
@@ -129,7 +130,7 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
         offset += nky * nkx * co * ci
     taps = sum(ph[4] * ph[5] for ph in plan.phases)
-    label = f'conv2d[{plan.kind} {plan.kh}x{plan.kw} in{plan.in_step} out{plan.out_step} {ci}->{co} @{oh}]'
+    label = f'conv2d_mfma_kernel<{_DTYPE_NAME[x.dtype]},{4 if co > 16 else 1}>'
     _lib.launch('sg_conv2d', p, x, label, _lib.nbytes(x, y), flops=2.0 * n * co * ci * taps * (oh * ow) / len(plan.phases))
     return y
 
@@ -163,6 +164,6 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None):
         p = Conv2dWgradParams(x=_lib.ptr(x), g=_lib.ptr(g), dw=_lib.ptr(dw), x_scale=_lib.ptr(x_scale),
                               g_scale=_lib.ptr(g_scale), dtype=_lib.dtype_code(x), n=n, cx=cx, h=h, w_in=w, cg=cg,
                               gh=gh, gw=gw, step=stride, dy0=-padding, dx0=-padding, nky=kh, nkx=kw)
-        label = f'conv2d_wgrad[{kh}x{kw} step{stride} {cx}x{cg} @{gh}]'
+        label = f'conv2d_wgrad_kernel<{_DTYPE_NAME[x.dtype]},{1 if kh * kw <= 1 else 4 if kh * kw <= 4 else 9}>'
         _lib.launch('sg_conv2d_wgrad', p, x, label, _lib.nbytes(x, g), flops=2.0 * n * cg * cx * kh * kw * gh * gw)
     return dw.permute(2, 3, 0, 1)

@@ -26,7 +26,7 @@ def _call(fn_name, x, dy, out, g, f):
     n, c, h, w = x.shape
     p = _lib.MbstdParams(x=_lib.ptr(x), dy=_lib.ptr(dy), out=_lib.ptr(out), dtype=_lib.dtype_code(x),
                          n=n, c=c, hw=h * w, g=g, f=f)
-    _lib.launch(fn_name, p, x, fn_name, _lib.nbytes(x, dy, out))
+    _lib.launch(fn_name, p, x, 'mbstd_kernel', _lib.nbytes(x, dy, out))
 
 
 class _MinibatchStd(torch.autograd.Function):
