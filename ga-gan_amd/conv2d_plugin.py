@@ -130,7 +130,7 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
         offset += nky * nkx * co * ci
     taps = sum(ph[4] * ph[5] for ph in plan.phases)
-    label = f'conv2d_mfma_kernel<{_DTYPE_NAME[x.dtype]},{4 if co > 16 else 1}>'
+    label = f'conv2d_mfma_kernel<{_DTYPE_NAME[x.dtype]}>'
     _lib.launch('sg_conv2d', p, x, label, _lib.nbytes(x, y), flops=2.0 * n * co * ci * taps * (oh * ow) / len(plan.phases))
     return y
 

@@ -120,6 +120,91 @@ __device__ __forceinline__ void stage_pixels(unsigned char* s_dst, const T* __re
     }
 }
 
+__device__ __forceinline__ int floor_div_i(int a, int b) {
+    int q = a / b;
+    return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+// Vector form of stage_pixels for rows that are a whole number of 16-byte packets (w % (16 /
+// sizeof(T)) == 0, 16-byte aligned base): a lane loads one aligned 16-byte packet (8 or 4
+// consecutive pixels) per channel - two channels at a time for 16-bit types - scales it, and
+// scatters its pixels into the [pixel][channel] image.  Lanes run over channels fastest, so a
+// wave's LDS stores land in consecutive banks, and its loads touch one or two cache lines per
+// channel plane.
+template <class T>
+__device__ __forceinline__ void stage_pixels_vec(unsigned char* s_dst, const T* __restrict__ x,
+                                                 const float* __restrict__ scale, int n_total, int c_total, int h,
+                                                 int w, int c0, int img0, int imgs, int iy0, int ix0, int lh, int lw) {
+    constexpr int VEC = 16 / (int)sizeof(T);            // pixels per packet
+    constexpr int KCH = kChunkBytes / (int)sizeof(T);   // channels per chunk
+    constexpr int CPL = (sizeof(T) == 2) ? 2 : 1;       // channels a lane handles at once (one LDS dword)
+    constexpr int CG = KCH / CPL;                       // = 16 lane slots across the chunk's channels
+    static_assert(CG == 16, "chunk is 16 dwords per pixel");
+    const int64_t plane = (int64_t)h * w;
+    const int vx0 = floor_div_i(ix0, VEC);
+    const int nv = floor_div_i(ix0 + lw - 1, VEC) - vx0 + 1;
+    const int items = imgs * lh * nv * CG;
+    for (int it = threadIdx.x; it < items; it += kThreads) {
+        const int cg = it & (CG - 1);
+        int r = it >> 4;
+        const int v = r % nv; r /= nv;
+        const int ry = r % lh;
+        const int ri = r / lh;
+        const int iy = iy0 + ry, n = img0 + ri, px0 = (vx0 + v) * VEC;
+        const int c = c0 + cg * CPL;
+        const bool ok = iy >= 0 && iy < h && n < n_total && px0 >= 0 && px0 < w && c < c_total;
+        uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+        if (ok) {
+            const T* src = x + ((int64_t)n * c_total + c) * plane + (int64_t)iy * w + px0;
+            va = *reinterpret_cast<const uint4*>(src);
+            if (CPL == 2 && c + 1 < c_total) vb = *reinterpret_cast<const uint4*>(src + plane);
+        }
+        unsigned out[VEC];   // one dword per pixel: (channel c, channel c+1) or one float
+        if constexpr (sizeof(T) == 2) {
+            const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+            if (scale && ok) {
+                const float s0 = scale[(int64_t)n * c_total + c];
+                const float s1 = (c + 1 < c_total) ? scale[(int64_t)n * c_total + c + 1] : 0.f;
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const unsigned short ea = (unsigned short)(wa[j >> 1] >> (16 * (j & 1)));
+                    const unsigned short eb = (unsigned short)(wb[j >> 1] >> (16 * (j & 1)));
+                    const T ha = Elem<T>::store(Elem<T>::load(__builtin_bit_cast(T, ea)) * s0);
+                    const T hb = Elem<T>::store(Elem<T>::load(__builtin_bit_cast(T, eb)) * s1);
+                    out[j] = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; j += 2) {
+                    out[j] = (wa[j >> 1] & 0xffffu) | (wb[j >> 1] << 16);
+                    out[j + 1] = (wa[j >> 1] >> 16) | (wb[j >> 1] & 0xffff0000u);
+                }
+            }
+        } else {
+            const unsigned wa[4] = {va.x, va.y, va.z, va.w};
+            const float s0 = (scale && ok) ? scale[(int64_t)n * c_total + c] : 1.f;
+#pragma unroll
+            for (int j = 0; j < VEC; j++) out[j] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, wa[j]) * s0);
+        }
+        unsigned char* row = s_dst + ((ri * lh + ry) * lw) * kPitch + cg * 4;
+        const int rx0 = px0 - ix0;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            const int rx = rx0 + j;
+            if (rx >= 0 && rx < lw) *reinterpret_cast<unsigned*>(row + rx * kPitch) = out[j];
+        }
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void stage_tile(unsigned char* s_dst, const T* __restrict__ x, const float* __restrict__ scale,
+                                           int n_total, int c_total, int h, int w, int c0, int img0, int imgs, int iy0,
+                                           int ix0, int lh, int lw) {
+    const bool vec = (w % (16 / (int)sizeof(T)) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    if (vec) stage_pixels_vec<T>(s_dst, x, scale, n_total, c_total, h, w, c0, img0, imgs, iy0, ix0, lh, lw);
+    else stage_pixels<T>(s_dst, x, scale, n_total, c_total, h, w, c0, img0, imgs, iy0, ix0, lh, lw);
+}
+
 template <class T, int M_TILES>
 __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_params p, Tile t) {
     using S = float;
@@ -174,7 +259,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     const bool w_vec = (p.ci % (16 / (int)sizeof(T)) == 0);
     for (int c0 = 0; c0 < p.ci; c0 += KCH) {
         __syncthreads();   // everyone is done reading the previous chunk
-        stage_pixels<T>(s_in, x, p.in_scale, p.n, p.ci, p.h, p.w_in, c0, img0, t.imgs, iy0, ix0, lh, lw);
+        stage_tile<T>(s_in, x, p.in_scale, p.n, p.ci, p.h, p.w_in, c0, img0, t.imgs, iy0, ix0, lh, lw);
         // ---- stage the weight chunk: [tap][BM][channel] ----------------------------------------
         if (w_vec) {
             for (int e = tid; e < taps * BM * 4; e += kThreads) {
@@ -283,7 +368,9 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     t.tiles_a = (AH + t.th - 1) / t.th;
     t.tiles_img = (p.n + t.imgs - 1) / t.imgs;
 
-    const int m_tiles = (p.co > 16) ? 4 : 1;
+    // 64 output channels per workgroup, unless that leaves most of the 256 CUs without a workgroup
+    const int64_t tiles_px = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img * p.num_phases;
+    const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) >= 256) ? 4 : 1;
     const int BM = 16 * m_tiles;
     const size_t lds = (size_t)t.imgs * t.lh * t.lw * kPitch + (size_t)max_taps * BM * kPitch;
     SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
@@ -376,9 +463,9 @@ __global__ void __launch_bounds__(kThreads) conv2d_wgrad_kernel(sg_conv2d_wgrad_
         const int img0 = rest * t.imgs;
         const int a0 = ta * t.th, b0 = tb * t.tw;
         __syncthreads();
-        stage_pixels<T>(s_x, x, p.x_scale, p.n, p.cx, p.h, p.w_in, cx0, img0, t.imgs, a0 * p.step + p.dy0,
+        stage_tile<T>(s_x, x, p.x_scale, p.n, p.cx, p.h, p.w_in, cx0, img0, t.imgs, a0 * p.step + p.dy0,
                         b0 * p.step + p.dx0, lh, lw);
-        stage_pixels<T>(s_g, g, p.g_scale, p.n, p.cg, p.gh, p.gw, cg0, img0, t.imgs, a0, b0, t.th, t.tw);
+        stage_tile<T>(s_g, g, p.g_scale, p.n, p.cg, p.gh, p.gw, cg0, img0, t.imgs, a0, b0, t.th, t.tw);
         __syncthreads();
 
 #pragma unroll

@@ -49,17 +49,18 @@ def _native_cfg(input, weight, bias, stride, padding, output_padding, dilation, 
         return None
     (sy, sx), (py, px), (oy, ox), (dy, dx) = _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
-    if sy != sx or py != px or oy != ox or (dy, dx) != (1, 1) or sy not in (1, 2) or kh * kw > 9 or py < 0:
+    if sy != sx or py != px or oy < 0 or ox < 0 or (dy, dx) != (1, 1) or sy not in (1, 2) or kh * kw > 9 or py < 0:
         return None
     if transpose and py > min(kh, kw) - 1:
         return None
-    return sy, py, oy, kh, kw
+    return sy, py, (oy, ox), kh, kw
 
 
 class _Conv2d(torch.autograd.Function):
     """cfg = (transpose, stride, padding, out_hw, kh, kw).  transpose=False: weight is [co, ci, kh, kw];
-    transpose=True: weight is [ci, co, kh, kw] (torch's conv_transpose2d layout) and out_hw is the
-    output size (it fixes the output padding)."""
+    transpose=True: weight is [ci, co, kh, kw] (torch's conv_transpose2d layout).  out_hw is the output
+    size: for a transposed convolution it fixes the output padding, for a plain one it may be smaller
+    than the natural size (trailing input rows / columns are then never read)."""
 
     @staticmethod
     def forward(ctx, input, weight, cfg):
@@ -67,7 +68,7 @@ class _Conv2d(torch.autograd.Function):
         x = input.contiguous()
         if not transpose:
             plan = _plugin.plan_conv(kh, kw, stride=stride, padding=padding)
-            y = _plugin.conv2d(x, plan.pack(weight), plan, weight.shape[0])
+            y = _plugin.conv2d(x, plan.pack(weight), plan, weight.shape[0], out_hw=out_hw)
         else:
             plan = _plugin.plan_conv_transpose(kh, kw, stride=stride, padding=padding)
             y = _plugin.conv2d(x, plan.pack(weight, transposed_layout=True), plan, weight.shape[1], out_hw=out_hw)
@@ -84,7 +85,7 @@ class _Conv2d(torch.autograd.Function):
             if not transpose:   # rows / columns the strided window never reached get zero gradient
                 grad_input = _Conv2d.apply(grad_output, weight, (True, stride, padding, tuple(input.shape[2:]), kh, kw))
             else:
-                grad_input = _Conv2d.apply(grad_output, weight, (False, stride, padding, None, kh, kw))
+                grad_input = _Conv2d.apply(grad_output, weight, (False, stride, padding, tuple(input.shape[2:]), kh, kw))
             assert grad_input.shape == input.shape
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             grad_weight = _Conv2dGradWeight.apply(grad_output, input, ctx.cfg, weight.shape)
@@ -118,26 +119,33 @@ class _Conv2dGradWeight(torch.autograd.Function):
                 grad2_input = _Conv2d.apply(grad_output, grad2_grad_weight,
                                             (True, stride, padding, tuple(input.shape[2:]), kh, kw))
             else:
-                grad2_input = _Conv2d.apply(grad_output, grad2_grad_weight, (False, stride, padding, None, kh, kw))
+                grad2_input = _Conv2d.apply(grad_output, grad2_grad_weight,
+                                            (False, stride, padding, tuple(input.shape[2:]), kh, kw))
             assert grad2_input.shape == input.shape
         return grad2_grad_output, grad2_input, None, None
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, output_size=None):
+    """`output_size=(oh, ow)` (an extension of the reference's signature) computes only the leading part of
+    the output; the input rows / columns beyond its footprint are ignored and receive zero gradient."""
     cfg = _native_cfg(input, weight, bias, stride, padding, 0, dilation, groups, transpose=False)
     if cfg is not None:
         s, p, _, kh, kw = cfg
-        if (input.shape[2] + 2 * p - kh) // s + 1 >= 1 and (input.shape[3] + 2 * p - kw) // s + 1 >= 1:
-            return _Conv2d.apply(input, weight, (False, s, p, None, kh, kw))
+        natural = ((input.shape[2] + 2 * p - kh) // s + 1, (input.shape[3] + 2 * p - kw) // s + 1)
+        out_hw = natural if output_size is None else tuple(int(v) for v in output_size)
+        if 1 <= out_hw[0] <= natural[0] and 1 <= out_hw[1] <= natural[1]:
+            return _Conv2d.apply(input, weight, (False, s, p, out_hw, kh, kw))
+    assert output_size is None, 'output_size needs the native convolution kernel'
     return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
                                       dilation=dilation, groups=groups)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    """The native kernel accepts any output_padding >= 0 (the extra rows / columns are zero)."""
     cfg = _native_cfg(input, weight, bias, stride, padding, output_padding, dilation, groups, transpose=True)
     if cfg is not None:
         s, p, op, kh, kw = cfg
-        out_hw = ((input.shape[2] - 1) * s + kh - 2 * p + op, (input.shape[3] - 1) * s + kw - 2 * p + op)
+        out_hw = ((input.shape[2] - 1) * s + kh - 2 * p + op[0], (input.shape[3] - 1) * s + kw - 2 * p + op[1])
         if out_hw[0] >= 1 and out_hw[1] >= 1:
             return _Conv2d.apply(input, weight, (True, s, p, out_hw, kh, kw))
     return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,

@@ -9,12 +9,20 @@ from . import upfirdn2d
 from .upfirdn2d import _get_filter_size, _parse_padding
 
 
-def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
+ROW_ALIGN = 8   # pixels: rows of intermediates are padded to whole 16-byte packets of 16-bit elements
+
+
+def _align_extra(width):
+    """Zero columns to append so that `width` becomes a multiple of ROW_ALIGN."""
+    return (-width) % ROW_ALIGN
+
+
+def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, **extra):
     """`flip_weight=True` is correlation (what conv2d computes), False is true convolution."""
     if not flip_weight:
         w = w.flip([2, 3])
     op = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
-    return op(x, w, stride=stride, padding=padding, groups=groups)
+    return op(x, w, stride=stride, padding=padding, groups=groups, **extra)
 
 
 @misc.profiled_function
@@ -52,7 +60,15 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=pads, gain=up ** 2, flip_filter=flip_filter)
 
     if down > 1 and up == 1:                     # blur, then strided conv
-        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=pads, flip_filter=flip_filter)
+        # The blurred intermediate has an odd width (W + 1).  Blur a few extra zero-padded columns so its
+        # rows are whole 16-byte packets, and let the strided conv produce only the columns it would have
+        # produced anyway: same values, aligned vector loads in the convolution kernels.
+        out_h = (x.shape[2] + py0 + py1 - fh + 1 - kh) // down + 1
+        out_w = (x.shape[3] + px0 + px1 - fw + 1 - kw) // down + 1
+        extra = _align_extra(x.shape[3] + px0 + px1 - fw + 1) if (groups == 1 and x.is_cuda) else 0
+        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1 + extra, py0, py1], flip_filter=flip_filter)
+        if extra:
+            return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight, output_size=(out_h, out_w))
         return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
 
     if up > 1:                                   # transposed strided conv, then blur (and decimate)
@@ -67,9 +83,13 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         py1 -= kh - up
         pxt = max(min(-px0, -px1), 0)
         pyt = max(min(-py0, -py1), 0)
+        # The transposed conv's output has an odd width ((W - 1) * up + k - 2 * pxt).  Ask it for extra
+        # (all-zero) columns up to whole 16-byte packets and crop them again with the blur's padding.
+        natural_w = (x.shape[3] - 1) * up + kw - 2 * pxt
+        extra = _align_extra(natural_w) if (groups == 1 and x.is_cuda and x.dtype != torch.float64) else 0
         x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True,
-                            flip_weight=(not flip_weight))
-        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2,
+                            flip_weight=(not flip_weight), **(dict(output_padding=[0, extra]) if extra else {}))
+        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt - extra, py0 + pyt, py1 + pyt], gain=up ** 2,
                                 flip_filter=flip_filter)
         if down > 1:
             x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
