@@ -58,6 +58,7 @@ template <> struct Mma<float> {
 };
 
 struct Tile {
+    int split_k;          // > 1: input-channel chunks are divided over blockIdx.z, partial sums added atomically
     int tw, th, imgs;     // pixel tile in phase coordinates; tw * th * imgs == 256
     int tw_shift, th_shift;
     int lw, lh;           // LDS footprint of one image's tile (pixels)
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     const int lrow = lane & 15, lgrp = lane >> 4;
 
     // ---- which tile ------------------------------------------------------------------
-    const int phase = blockIdx.z;
+    const int phase = blockIdx.z % p.num_phases, ksplit = blockIdx.z / p.num_phases;
     const sg_conv2d_phase ph = p.phase[phase];
     const int AH = (p.oh - ph.oy0 + p.out_step - 1) / p.out_step;   // phase-local output extent
     const int AW = (p.ow - ph.ox0 + p.out_step - 1) / p.out_step;
@@ -257,7 +258,10 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const bool w_vec = (p.ci % (16 / (int)sizeof(T)) == 0);
-    for (int c0 = 0; c0 < p.ci; c0 += KCH) {
+    const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
+    const int c_begin = ksplit * chunks_per_split * KCH;
+    const int c_end = min(p.ci, c_begin + chunks_per_split * KCH);
+    for (int c0 = c_begin; c0 < c_end; c0 += KCH) {
         __syncthreads();   // everyone is done reading the previous chunk
         stage_tile<T>(s_in, x, p.in_scale, p.n, p.ci, p.h, p.w_in, c0, img0, t.imgs, iy0, ix0, lh, lw);
         // ---- stage the weight chunk: [tap][BM][channel] ----------------------------------------
@@ -328,7 +332,11 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
                 if (p.act == 3) v = (v > 0) ? v : v * p.alpha;
                 v *= p.gain;
                 if (p.clamp >= 0) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-                y[(((int64_t)n * p.co + ch) * p.oh + oy) * p.ow + ox] = Elem<T>::store(v);
+                T* dst = y + (((int64_t)n * p.co + ch) * p.oh + oy) * p.ow + ox;
+                if constexpr (sizeof(T) == 4) {
+                    if (t.split_k > 1) { atomicAdd(reinterpret_cast<float*>(dst), v); continue; }
+                }
+                *dst = Elem<T>::store(v);
             }
         }
     }
@@ -376,7 +384,21 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
     const int64_t tiles = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img;
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
-    dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)p.num_phases);
+    // Low-resolution float layers: few pixel tiles and a long K loop.  Without an epilogue the sum over input
+    // channels can be divided over workgroups that add into a zeroed output.
+    t.split_k = 1;
+    const bool plain = !p.in_scale && !p.out_scale && !p.bias && !p.noise && p.act == 1 && p.gain == 1.f && p.clamp < 0;
+    if (sizeof(T) == 4 && plain) {
+        constexpr int KCH = kChunkBytes / (int)sizeof(T);
+        const int64_t blocks = tiles * ((p.co + BM - 1) / BM) * p.num_phases;
+        const int chunks = (p.ci + KCH - 1) / KCH;
+        while (t.split_k < 8 && blocks * t.split_k < 512 && chunks / (t.split_k * 2) >= 4) t.split_k *= 2;
+        if (t.split_k > 1) {
+            hipError_t e = hipMemsetAsync(p.y, 0, (size_t)p.n * p.co * p.oh * p.ow * sizeof(T), stream);
+            if (e != hipSuccess) return fail((int)e, "conv2d: cannot zero the output: %s", hipGetErrorString(e));
+        }
+    }
+    dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)(p.num_phases * t.split_k));
     auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
     if (lds > 64 * 1024) {   // opt in to large dynamic LDS (idempotent, cheap)
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -169,6 +169,119 @@ int launch_tiled(const sg_upfirdn2d_params& p, hipStream_t stream) {
     return check_launch("sg_upfirdn2d (tiled)");
 }
 
+
+// ---------------------------------------------------------------------------
+// Fast path for the most frequent instance: up = down = 1, filter up to 4x4 (the blur after
+// every up-sampling convolution and in front of every strided one).  One workgroup produces a
+// 64 x 32 output tile: the 67 x 35 input footprint is fetched with aligned 16-byte packets and
+// kept in LDS as float; every lane then produces 8 consecutive outputs of one row from four
+// 12-wide LDS row segments (three 16-byte reads per row) and writes them with one 16-byte store.
+template <class T>
+__global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_params p, int tiles_x, int tiles_y) {
+    constexpr int TW = 64, TH = 32, FW = 4, FH = 4;
+    constexpr int IN_W = TW + FW - 1, IN_H = TH + FH - 1, PITCH = 68;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) float s_x[IN_H * PITCH];
+    __shared__ float s_f[FH * FW];
+    const T* __restrict__ x = (const T*)p.x;
+    T* __restrict__ y = (T*)p.y;
+    const int tid = threadIdx.x;
+    if (tid < FH * FW) {
+        const int fy = tid / FW, fx = tid % FW;
+        float v = 0;
+        if (fx < p.f_w && fy < p.f_h) {
+            const int sx = p.flip ? fx : p.f_w - 1 - fx, sy = p.flip ? fy : p.f_h - 1 - fy;
+            v = p.f[(int64_t)sx * p.f_stride_w + (int64_t)sy * p.f_stride_h];
+        }
+        s_f[tid] = v * p.gain;
+    }
+    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const int out_x0 = tile_x * TW, out_y0 = tile_y * TH;
+    const int in_x0 = out_x0 - p.pad_x0, in_y0 = out_y0 - p.pad_y0;
+    // aligned packets that cover [in_x0, in_x0 + IN_W)
+    const int vx0 = (in_x0 >= 0) ? in_x0 / VEC : -((-in_x0 + VEC - 1) / VEC);
+    const int nv = (in_x0 + IN_W - 1 - vx0 * VEC) / VEC + 1;
+    const bool vec_in = (p.in_stride_h % VEC == 0) && (p.in_stride_c % VEC == 0) && (p.in_stride_n % VEC == 0) &&
+                        (p.in_w % VEC == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    const bool vec_out = (p.out_stride_h % VEC == 0) && (p.out_stride_c % VEC == 0) && (p.out_stride_n % VEC == 0) &&
+                         ((reinterpret_cast<uintptr_t>(y) & 15u) == 0);
+    const int planes = p.in_n * p.in_c;
+    const int lx = (tid & 7) * 8, ly = tid >> 3;   // this lane's 8 outputs: row ly, columns lx .. lx+7
+
+    for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+        const int n = plane / p.in_c, c = plane - n * p.in_c;
+        const T* xp = x + (int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c;
+        T* yp = y + (int64_t)n * p.out_stride_n + (int64_t)c * p.out_stride_c;
+        __syncthreads();
+        if (vec_in) {
+            for (int it = tid; it < IN_H * nv; it += 256) {
+                const int ry = it / nv, v = it - ry * nv;
+                const int iy = in_y0 + ry, px0 = (vx0 + v) * VEC;
+                Pack<T> pk;
+                const bool ok = iy >= 0 && iy < p.in_h && px0 >= 0 && px0 < p.in_w;
+                if (ok) pk = load_pack(xp + (int64_t)iy * p.in_stride_h + px0);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const int rx = px0 + j - in_x0;
+                    if (rx >= 0 && rx < IN_W) s_x[ry * PITCH + rx] = ok ? (float)Elem<T>::load(pk.v[j]) : 0.f;
+                }
+            }
+        } else {
+            for (int it = tid; it < IN_H * IN_W; it += 256) {
+                const int ry = it / IN_W, rx = it - ry * IN_W;
+                const int ix = in_x0 + rx, iy = in_y0 + ry;
+                float v = 0;
+                if (ix >= 0 && iy >= 0 && ix < p.in_w && iy < p.in_h) v = (float)Elem<T>::load(xp[(int64_t)iy * p.in_stride_h + ix]);
+                s_x[ry * PITCH + rx] = v;
+            }
+        }
+        __syncthreads();
+
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+#pragma unroll
+        for (int fy = 0; fy < FH; fy++) {
+            const float4* row = reinterpret_cast<const float4*>(s_x + (ly + fy) * PITCH + lx);
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+            const float in[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+            for (int fx = 0; fx < FW; fx++) {
+                const float tap = s_f[fy * FW + fx];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] += in[j + fx] * tap;
+            }
+        }
+        const int oy = out_y0 + ly, ox = out_x0 + lx;
+        if (oy < p.out_h && ox < p.out_w) {
+            T* dst = yp + (int64_t)oy * p.out_stride_h + ox;
+            if (sizeof(T) == 2 && vec_out && ox + 8 <= p.out_w) {
+                Pack<T> out;
+#pragma unroll
+                for (int j = 0; j < 8; j++) out.v[j] = Elem<T>::store(acc[j]);
+                store_pack(dst, out);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (ox + j < p.out_w) dst[j] = Elem<T>::store(acc[j]);
+            }
+        }
+    }
+}
+
+template <class T>
+int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    const int tiles_x = (p.out_w + 63) / 64, tiles_y = (p.out_h + 31) / 32;
+    const int64_t planes = (int64_t)p.in_n * p.in_c, tiles = (int64_t)tiles_x * tiles_y;
+    SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
+    int64_t gy = planes;
+    if (tiles * gy > 8192) gy = (8192 + tiles - 1) / tiles;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T>), dim3((unsigned)tiles, (unsigned)gy), dim3(256), 0, stream, p, tiles_x, tiles_y);
+    return check_launch("sg_upfirdn2d (blur)");
+}
+
 template <class T>
 int launch_generic(const sg_upfirdn2d_params& p, hipStream_t stream) {
     const int64_t total = (int64_t)p.out_w * p.out_h * p.in_c * p.in_n;
@@ -183,7 +296,7 @@ int launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
     const bool rows_contiguous = p.in_stride_w == 1 && p.out_stride_w == 1;
     if (rows_contiguous && sizeof(T) <= 4 && p.f_w <= 4 && p.f_h <= 4) {
         const int ux = p.up_x, uy = p.up_y, dx = p.down_x, dy = p.down_y;
-        if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return launch_tiled<T, 1, 1, 1, 1, 4, 4, 64, 16>(p, stream);
+        if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return launch_blur4<T>(p, stream);
         if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return launch_tiled<T, 2, 2, 1, 1, 4, 4, 64, 16>(p, stream);
         if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return launch_tiled<T, 1, 1, 2, 2, 4, 4, 64, 8>(p, stream);
     }
