@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsgops.so')
 
 SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
-           'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad')
+           'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad', 'sg_upfirdn2d_epilogue',
+           'sg_epilogue_backward', 'sg_conv2d_reduce_rows')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -64,9 +65,13 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = [ctypes.POINTER(struct), vp]
             fn.restype = ctypes.c_int
-        for name in ('sg_conv2d', 'sg_conv2d_wgrad'):     # structs declared in conv2d_plugin.py
+        handle.sg_upfirdn2d_epilogue.argtypes = [ctypes.POINTER(Upfirdn2dParams), vp, vp]
+        handle.sg_upfirdn2d_epilogue.restype = ctypes.c_int
+        for name in ('sg_conv2d', 'sg_conv2d_wgrad', 'sg_epilogue_backward'):     # structs declared in the plugin modules
             getattr(handle, name).argtypes = [vp, vp]
             getattr(handle, name).restype = ctypes.c_int
+        handle.sg_conv2d_reduce_rows.argtypes = [vp]
+        handle.sg_conv2d_reduce_rows.restype = ctypes.c_int
         _lib = handle
     return _lib
 
@@ -124,6 +129,20 @@ def launch(fn_name, params, ref, label=None, nbytes=0, flops=0.0):
             end.record()
             _profile.append((label or fn_name, nbytes, start, end, flops))
     check(rc, fn_name)
+
+
+def launch_raw(call, ref, what, label, nbytes=0, flops=0.0):
+    """Like `launch` for entry points with a different argument list: `call(stream)` returns the status."""
+    with torch.cuda.device(ref.device):
+        if _profile is None:
+            rc = call(stream_of(ref))
+        else:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            rc = call(stream_of(ref))
+            end.record()
+            _profile.append((label, nbytes, start, end, flops))
+    check(rc, what)
 
 
 def nbytes(*tensors):

@@ -23,7 +23,8 @@ class Conv2dParams(ctypes.Structure):
                 ('co', ctypes.c_int32), ('oh', ctypes.c_int32), ('ow', ctypes.c_int32),
                 ('in_step', ctypes.c_int32), ('out_step', ctypes.c_int32), ('num_phases', ctypes.c_int32),
                 ('phase', Phase * 4),
-                ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float)]
+                ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
+                ('reduce_x', ctypes.c_void_p), ('reduce_out', ctypes.c_void_p)]
 
 
 class Plan:
@@ -86,9 +87,11 @@ _DTYPE_NAME = {torch.float32: 'float', torch.float16: '__half', torch.bfloat16: 
 
 
 def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
-           act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None):
+           act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None, reduce_x=None):
     """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow].
-    `out_hw` overrides the plan's natural output size (pixels whose taps all fall outside x are zero)."""
+    `out_hw` overrides the plan's natural output size (pixels whose taps all fall outside x are zero).
+    With `reduce_x` (y's shape and dtype) the call returns (y, r), r[n, co] = sum over pixels of
+    reduce_x * (the contraction before out_scale and the epilogue), float32."""
     if not x.is_cuda:
         raise RuntimeError('x must reside on CUDA device')
     if x.dim() != 4 or not x.is_contiguous():
@@ -120,18 +123,30 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device)
     if y.numel() == 0:
         return y
+    if reduce_x is not None and (reduce_x.shape != y.shape or reduce_x.dtype != x.dtype or not reduce_x.is_contiguous()):
+        raise RuntimeError('reduce_x must be dense and match the output')
     p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(w_packed), y=_lib.ptr(y), in_scale=_lib.ptr(in_scale),
                      out_scale=_lib.ptr(out_scale), bias=_lib.ptr(bias), noise=_lib.ptr(noise),
                      noise_gain=_lib.ptr(noise_gain), noise_stride_n=noise_stride, dtype=_lib.dtype_code(x),
                      n=n, ci=ci, h=h, w_in=w, co=co, oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step,
-                     num_phases=len(plan.phases), act=ACT_INDEX[act], alpha=alpha, gain=gain, clamp=clamp)
+                     num_phases=len(plan.phases), act=ACT_INDEX[act], alpha=alpha, gain=gain, clamp=clamp,
+                     reduce_x=_lib.ptr(reduce_x), reduce_out=None)
     offset = 0
     for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
         offset += nky * nkx * co * ci
+    partial = None
+    if reduce_x is not None:
+        rows = _lib.lib().sg_conv2d_reduce_rows(ctypes.byref(p))
+        if rows < 1:
+            raise RuntimeError('sg_conv2d_reduce_rows rejected the geometry')
+        partial = torch.zeros([n, rows, co], dtype=torch.float32, device=x.device)
+        p.reduce_out = _lib.ptr(partial)
     taps = sum(ph[4] * ph[5] for ph in plan.phases)
     label = f'conv2d_mfma_kernel<{_DTYPE_NAME[x.dtype]}>'
-    _lib.launch('sg_conv2d', p, x, label, _lib.nbytes(x, y), flops=2.0 * n * co * ci * taps * (oh * ow) / len(plan.phases))
+    _lib.launch('sg_conv2d', p, x, label, _lib.nbytes(x, y, reduce_x), flops=2.0 * n * co * ci * taps * (oh * ow) / len(plan.phases))
+    if reduce_x is not None:
+        return y, (partial.sum(dim=1) if partial.shape[1] > 1 else partial[:, 0])
     return y
 
 

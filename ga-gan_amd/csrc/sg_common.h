@@ -62,7 +62,7 @@ template <class T> __device__ __forceinline__ void store_pack(T* p, const Pack<T
     *reinterpret_cast<Pack<T>*>(p) = v;
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Dispatch a callable templated on the storage type.
 #define SG_DISPATCH_DTYPE(dtype, ALLOW_F64, ...)                                   \

@@ -308,6 +308,11 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     // ---- epilogue: scale, noise, bias, activation, gain, clamp; one store per element ----------
     const S noise_gain = (p.noise && p.noise_gain) ? *p.noise_gain : (S)1;
     T* __restrict__ y = (T*)p.y;
+    S red[M_TILES][4];   // per-lane share of sum_pixels acc * reduce_x
+#pragma unroll
+    for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[m][r] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int slot = wave * 64 + j * 16 + lrow;
@@ -315,7 +320,14 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         const int ra = (slot >> t.tw_shift) & (t.th - 1);
         const int n = img0 + (slot >> (t.tw_shift + t.th_shift));
         const int a = a0 + ra, b = b0 + rb;
-        if (a >= AH || b >= AW || n >= p.n) continue;
+        if (t.imgs > 1) {   // n-tiles of a low-resolution tile belong to different images: flush per n-tile
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[m][r] = 0;
+        }
+        const bool live = !(a >= AH || b >= AW || n >= p.n);
+        if (live) {
         const int oy = ph.oy0 + a * p.out_step, ox = ph.ox0 + b * p.out_step;
         S nz = 0;
         if (p.noise) nz = p.noise[(int64_t)n * p.noise_stride_n + (int64_t)oy * p.ow + ox] * noise_gain;
@@ -326,6 +338,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
                 const int ch = m0 + m * 16 + lgrp * 4 + r;
                 if (ch >= p.co) continue;
                 S v = acc[m][j][r];
+                if (p.reduce_out) red[m][r] += v * Elem<T>::load(((const T*)p.reduce_x)[(((int64_t)n * p.co + ch) * p.oh + oy) * p.ow + ox]);
                 if (p.out_scale) v *= p.out_scale[(int64_t)n * p.co + ch];
                 v += nz;
                 if (p.bias) v += Elem<T>::load(((const T*)p.bias)[ch]);
@@ -339,6 +352,40 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
                 *dst = Elem<T>::store(v);
             }
         }
+        }   // live
+        if (p.reduce_out && t.imgs > 1) {   // 16 lanes = 16 pixels of one image: shuffle-reduce, one atomic per channel
+            const int n_tile = img0 + ((wave * 64 + j * 16) >> (t.tw_shift + t.th_shift));
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    S v = red[m][r];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    const int ch = m0 + m * 16 + lgrp * 4 + r;
+                    if (lrow == 0 && ch < p.co && n_tile < p.n && v != 0) atomicAdd(p.reduce_out + (int64_t)n_tile * p.co + ch, v);
+                }
+        }
+    }
+    if (p.reduce_out && t.imgs == 1) {
+        // The whole tile lies in one image: reduce over the wave's lanes, then over the four waves through LDS,
+        // and store one partial row per (image, tile, phase) - no atomics, the caller sums the rows.
+        __syncthreads();   // every wave has left the MFMA loop; LDS can be reused
+        float* s_red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                S v = red[m][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (lrow == 0) s_red[wave * BM + m * 16 + lgrp * 4 + r] = v;
+            }
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.co && img0 < p.n) {
+            const float v = s_red[tid] + s_red[BM + tid] + s_red[2 * BM + tid] + s_red[3 * BM + tid];
+            const int rows = t.tiles_a * t.tiles_b * p.num_phases;
+            const int row = (ta * t.tiles_b + tb) * p.num_phases + phase;
+            p.reduce_out[((int64_t)img0 * rows + row) * p.co + m0 + tid] = v;
+        }
     }
 }
 
@@ -348,9 +395,8 @@ int ilog2(int v) {
     return s;
 }
 
-template <class T>
-int launch(const sg_conv2d_params& p, hipStream_t stream) {
-    // Phase-local output extent (largest phase) decides the pixel tile.
+// Phase-local output extent (largest phase) decides the pixel tile.
+Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     int AH = 0, AW = 0, max_taps = 0, max_nky = 0, max_nkx = 0;
     for (int i = 0; i < p.num_phases; i++) {
         const sg_conv2d_phase& ph = p.phase[i];
@@ -361,6 +407,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
         max_nkx = max(max_nkx, ph.nkx);
     }
     Tile t;
+    t.split_k = 1;
     t.tw = 32;
     while (t.tw > 1 && t.tw / 2 >= AW) t.tw /= 2;              // smallest power of two covering AW, at most 32
     int rest = kPixels / t.tw;
@@ -376,6 +423,14 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     t.tiles_a = (AH + t.th - 1) / t.th;
     t.tiles_img = (p.n + t.imgs - 1) / t.imgs;
 
+    *out_max_taps = max_taps;
+    return t;
+}
+
+template <class T>
+int launch(const sg_conv2d_params& p, hipStream_t stream) {
+    int max_taps = 0;
+    Tile t = make_tile(p, &max_taps);
     // 64 output channels per workgroup, unless that leaves most of the 256 CUs without a workgroup
     const int64_t tiles_px = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img * p.num_phases;
     const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) >= 256) ? 4 : 1;
@@ -625,4 +680,11 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
         case SG_BF16: return launch_wgrad<__hip_bfloat16>(*p, (hipStream_t)stream);
     }
     return fail(SG_ERR_UNSUPPORTED, "conv2d_wgrad: dtype %d is not supported (f32, f16, bf16)", p->dtype);
+}
+
+extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
+    if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return -1;
+    int taps = 0;
+    const sg::Tile t = sg::make_tile(*p, &taps);
+    return (t.imgs == 1) ? t.tiles_a * t.tiles_b * p->num_phases : 1;
 }

@@ -1,0 +1,103 @@
+// Backward of the layer epilogue  y = clamp(act(v * scale[n,c] + noise * noise_gain + bias[c]) * gain)
+// in one pass over dy and y: the gradient w.r.t. v, and the reductions that give the gradients of
+// the bias, of the per-sample scale (demodulation coefficients) and of the noise strength.  The
+// pre-activation value is recovered from the saved output (leaky ReLU is invertible; where the
+// output was clamped the gradient is zero and the value does not matter), so nothing but y is
+// kept from the forward pass.  One workgroup per (sample, channel) plane; HBM-bound: reads dy and
+// y once, writes dz once.
+#include "sg_common.h"
+
+namespace sg {
+namespace {
+
+template <class T>
+__global__ void __launch_bounds__(256) epilogue_bwd_kernel(sg_epilogue_bwd_params p) {
+    constexpr int VEC = Pack<T>::N;
+    __shared__ float scratch[3][256 / kWave];
+    const int plane = blockIdx.x;
+    const int n = plane / p.c, c = plane - n * p.c;
+    const int hw = p.h * p.w;
+    const sg_epilogue& ep = p.ep;
+    const float scale = ep.scale ? ep.scale[plane] : 1.f;
+    const float bias = ep.bias ? (float)Elem<T>::load(((const T*)ep.bias)[c]) : 0.f;
+    const float ng = (ep.noise && ep.noise_gain) ? *ep.noise_gain : 1.f;
+    const float* __restrict__ nz = ep.noise ? ep.noise + (int64_t)n * ep.noise_stride_n : nullptr;
+    const T* __restrict__ dy = (const T*)p.dy + (int64_t)plane * hw;
+    const T* __restrict__ y = (const T*)p.y + (int64_t)plane * hw;
+    T* __restrict__ dz = (T*)p.dz + (int64_t)plane * hw;
+    const float inv_gain = (ep.gain != 0.f) ? 1.f / ep.gain : 0.f;
+    const float inv_alpha = (ep.alpha != 0.f) ? 1.f / ep.alpha : 0.f;
+    float sum_g = 0.f, sum_gv = 0.f, sum_gn = 0.f;
+
+    auto one = [&](float yv, float dyv, int i) -> float {
+        float g = dyv * ep.gain;
+        if (ep.act == 3 && !(yv > 0.f)) g *= ep.alpha;
+        if (ep.clamp >= 0.f && !(yv > -ep.clamp && yv < ep.clamp)) g = 0.f;
+        sum_g += g;
+        const float noise = nz ? nz[i] : 0.f;
+        if (p.dscale) {
+            float t = yv * inv_gain;                       // act(pre-activation)
+            if (ep.act == 3 && t < 0.f) t *= inv_alpha;    // pre-activation
+            sum_gv += g * (t - noise * ng - bias);         // = g * v * scale
+        }
+        sum_gn += g * noise;
+        return g * scale;
+    };
+
+    const bool vec = (hw % VEC == 0) && aligned16(p.dy) && aligned16(p.y) && aligned16(p.dz);
+    if (vec) {
+        for (int k = threadIdx.x; k < hw / VEC; k += blockDim.x) {
+            const Pack<T> vy = load_pack(y + k * VEC), vd = load_pack(dy + k * VEC);
+            Pack<T> out;
+#pragma unroll
+            for (int j = 0; j < VEC; j++)
+                out.v[j] = Elem<T>::store(one((float)Elem<T>::load(vy.v[j]), (float)Elem<T>::load(vd.v[j]), k * VEC + j));
+            store_pack(dz + k * VEC, out);
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += blockDim.x)
+            dz[i] = Elem<T>::store(one((float)Elem<T>::load(y[i]), (float)Elem<T>::load(dy[i]), i));
+    }
+
+    float sums[3] = {sum_g, sum_gv, sum_gn};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        float v = sums[q];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) scratch[q][threadIdx.x / kWave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot[3] = {0.f, 0.f, 0.f};
+        for (int q = 0; q < 3; q++)
+            for (int wv = 0; wv < (int)(blockDim.x / kWave); wv++) tot[q] += scratch[q][wv];
+        if (p.dbias) atomicAdd(p.dbias + c, tot[0]);
+        if (p.dscale) p.dscale[plane] = tot[1] / scale;
+        if (p.dnoise_gain && nz) atomicAdd(p.dnoise_gain, tot[2]);
+    }
+}
+
+}  // namespace
+}  // namespace sg
+
+extern "C" int sg_epilogue_backward(const sg_epilogue_bwd_params* p, sg_stream_t stream) {
+    using namespace sg;
+    SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
+    SG_REQUIRE(p->n >= 0 && p->c >= 1 && p->h >= 1 && p->w >= 1, SG_ERR_INVALID_ARGUMENT, "epilogue_backward: bad sizes");
+    SG_REQUIRE((int64_t)p->n * p->c * p->h * p->w <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "epilogue_backward: tensor is too large");
+    SG_REQUIRE(p->ep.act == 1 || p->ep.act == 3, SG_ERR_UNSUPPORTED, "epilogue activation must be linear (1) or lrelu (3)");
+    SG_REQUIRE(!p->dscale || p->ep.scale, SG_ERR_INVALID_ARGUMENT, "epilogue_backward: dscale needs the forward's scale");
+    SG_REQUIRE(!(p->dscale && p->ep.act == 3 && p->ep.alpha == 0.f), SG_ERR_UNSUPPORTED,
+               "epilogue_backward: dscale with alpha = 0 (the activation is not invertible)");
+    if (p->n == 0) return SG_OK;
+    SG_REQUIRE(p->dy && p->y && p->dz, SG_ERR_NULL_POINTER, "epilogue_backward: dy, y and dz must not be NULL");
+    dim3 grid((unsigned)(p->n * p->c));
+    switch (p->dtype) {
+        case SG_F32: hipLaunchKernelGGL((epilogue_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, *p); break;
+        case SG_F16: hipLaunchKernelGGL((epilogue_bwd_kernel<__half>), grid, dim3(256), 0, (hipStream_t)stream, *p); break;
+        case SG_BF16: hipLaunchKernelGGL((epilogue_bwd_kernel<__hip_bfloat16>), grid, dim3(256), 0, (hipStream_t)stream, *p); break;
+        default: return fail(SG_ERR_UNSUPPORTED, "epilogue_backward: dtype %d is not supported", p->dtype);
+    }
+    return check_launch("sg_epilogue_backward");
+}

@@ -177,7 +177,8 @@ int launch_tiled(const sg_upfirdn2d_params& p, hipStream_t stream) {
 // kept in LDS as float; every lane then produces 8 consecutive outputs of one row from four
 // 12-wide LDS row segments (three 16-byte reads per row) and writes them with one 16-byte store.
 template <class T>
-__global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_params p, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_params p, int tiles_x, int tiles_y, sg_epilogue ep,
+                                                              bool has_ep) {
     constexpr int TW = 64, TH = 32, FW = 4, FH = 4;
     constexpr int IN_W = TW + FW - 1, IN_H = TH + FH - 1, PITCH = 68;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -253,6 +254,21 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
             }
         }
         const int oy = out_y0 + ly, ox = out_x0 + lx;
+        if (has_ep && oy < p.out_h && ox < p.out_w) {
+            const float sc = ep.scale ? ep.scale[(int64_t)n * p.in_c + c] : 1.f;
+            const float bias = ep.bias ? (float)Elem<T>::load(((const T*)ep.bias)[c]) : 0.f;
+            const float ng = (ep.noise && ep.noise_gain) ? *ep.noise_gain : 1.f;
+            const float* nz = ep.noise ? ep.noise + (int64_t)n * ep.noise_stride_n + (int64_t)oy * p.out_w + ox : nullptr;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float v = acc[j] * sc + bias;
+                if (nz && ox + j < p.out_w) v += nz[j] * ng;
+                if (ep.act == 3) v = (v > 0) ? v : v * ep.alpha;
+                v *= ep.gain;
+                if (ep.clamp >= 0) v = fminf(fmaxf(v, -ep.clamp), ep.clamp);
+                acc[j] = v;
+            }
+        }
         if (oy < p.out_h && ox < p.out_w) {
             T* dst = yp + (int64_t)oy * p.out_stride_h + ox;
             if (sizeof(T) == 2 && vec_out && ox + 8 <= p.out_w) {
@@ -270,7 +286,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
 }
 
 template <class T>
-int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream) {
+int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream, const sg_epilogue* ep = nullptr) {
     const int tiles_x = (p.out_w + 63) / 64, tiles_y = (p.out_h + 31) / 32;
     const int64_t planes = (int64_t)p.in_n * p.in_c, tiles = (int64_t)tiles_x * tiles_y;
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
@@ -278,7 +294,10 @@ int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream) {
     if (tiles * gy > 8192) gy = (8192 + tiles - 1) / tiles;
     if (gy > 65535) gy = 65535;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T>), dim3((unsigned)tiles, (unsigned)gy), dim3(256), 0, stream, p, tiles_x, tiles_y);
+    sg_epilogue e = {};
+    if (ep) e = *ep;
+    hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T>), dim3((unsigned)tiles, (unsigned)gy), dim3(256), 0, stream, p, tiles_x, tiles_y, e,
+                       ep != nullptr);
     return check_launch("sg_upfirdn2d (blur)");
 }
 
@@ -337,4 +356,24 @@ extern "C" int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream) {
     SG_REQUIRE(p->x && p->f && p->y, SG_ERR_NULL_POINTER, "x, f and y must not be NULL");
     SG_DISPATCH_DTYPE(p->dtype, true, return launch<T>(*p, (hipStream_t)stream));
     return SG_OK;
+}
+
+extern "C" int sg_upfirdn2d_epilogue(const sg_upfirdn2d_params* p, const sg_epilogue* ep, sg_stream_t stream) {
+    using namespace sg;
+    if (ep == nullptr) return sg_upfirdn2d(p, stream);
+    SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
+    SG_REQUIRE(p->up_x == 1 && p->up_y == 1 && p->down_x == 1 && p->down_y == 1 && p->f_w >= 1 && p->f_h >= 1 &&
+                   p->f_w <= 4 && p->f_h <= 4 && p->in_stride_w == 1 && p->out_stride_w == 1,
+               SG_ERR_UNSUPPORTED, "upfirdn2d with epilogue: only up = down = 1, filters up to 4x4, contiguous rows");
+    SG_REQUIRE(p->out_w >= 1 && p->out_h >= 1, SG_ERR_INVALID_ARGUMENT, "output must be at least 1x1");
+    SG_REQUIRE(ep->act == 1 || ep->act == 3, SG_ERR_UNSUPPORTED, "epilogue activation must be linear (1) or lrelu (3)");
+    SG_REQUIRE(!ep->noise || p->out_stride_h == p->out_w, SG_ERR_UNSUPPORTED, "epilogue noise needs a dense output");
+    if (p->in_c == 0 || p->in_n == 0) return SG_OK;
+    SG_REQUIRE(p->x && p->f && p->y, SG_ERR_NULL_POINTER, "x, f and y must not be NULL");
+    switch (p->dtype) {
+        case SG_F32: return launch_blur4<float>(*p, (hipStream_t)stream, ep);
+        case SG_F16: return launch_blur4<__half>(*p, (hipStream_t)stream, ep);
+        case SG_BF16: return launch_blur4<__hip_bfloat16>(*p, (hipStream_t)stream, ep);
+    }
+    return fail(SG_ERR_UNSUPPORTED, "upfirdn2d with epilogue: dtype %d is not supported", p->dtype);
 }

@@ -1,0 +1,209 @@
+"""One-kernel convolution layers: modulation, contraction, demodulation, noise, bias, leaky ReLU,
+gain and clamp in a single pass (two passes when the layer up-samples: transposed convolution,
+then blur with the epilogue), and a backward of three passes (epilogue backward with its
+reductions, data gradient with the style-gradient reduction, weight gradient).
+
+This is the training-path `modulated_conv2d` + `bias_act` of a synthesis layer
+(reference: training/networks.py:640-653 and 919-921), a to-RGB layer (:961-962) and a
+discriminator `Conv2dLayer` (:748-760) without their intermediate tensors.  When a
+higher-order graph is being recorded (path-length and R1 regularisation) the backward re-expresses
+the layer with the differentiable primitive ops instead, so gradients of any order stay available.
+"""
+import torch
+
+from ... import conv2d_plugin as _conv
+from ... import layer_plugin as _layer
+from ... import upfirdn2d_plugin as _fir
+from . import bias_act
+from . import conv2d_gradfix
+from . import fma
+from . import upfirdn2d
+from .conv2d_resample import _align_extra
+from .upfirdn2d import _get_filter_size
+
+
+MIN_FUSED_PIXELS_F32 = 1 << 15
+
+
+def supported(x, w, up, down, groups=1):
+    """Geometries the fused kernels cover; everything else takes the composite path."""
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.float16, torch.bfloat16) or w.dtype != x.dtype:
+        return False
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    if groups != 1 or kh != kw or kh not in (1, 3):
+        return False
+    # Low-resolution float32 layers have too few pixel tiles to fill the chip; the composite path lets their
+    # contraction split the channel sum over workgroups, which a fused epilogue cannot.
+    if x.dtype == torch.float32 and x.shape[0] * x.shape[2] * x.shape[3] * (up * up) // (down * down) < MIN_FUSED_PIXELS_F32:
+        return False
+    return (up, down) in ((1, 1), (1, 2)) or ((up, down) == (2, 1) and kh == 3)
+
+
+def _noise_plane(noise, dtype):
+    return None if noise is None else noise.to(torch.float32).contiguous()
+
+
+def _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg):
+    """The same layer from the differentiable primitive ops."""
+    mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
+    n = x.shape[0]
+    if styles is not None:
+        x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+    if mode == 'same':
+        c = conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding, output_size=out_hw)
+    else:
+        c = conv2d_gradfix.conv_transpose2d(x, w.transpose(0, 1), stride=2, padding=0, output_padding=[0, extra])
+        c = upfirdn2d.upfirdn2d(c, f, padding=list(blur_pad), gain=4)
+    nz = None
+    if noise is not None:
+        nz = (noise * noise_strength).to(x.dtype) if noise_strength is not None else noise.to(x.dtype)
+    if dcoefs is not None and nz is not None:
+        c = fma.fma(c, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), nz)
+    elif dcoefs is not None:
+        c = c * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
+    elif nz is not None:
+        c = c + nz
+    return bias_act.bias_act(c, bias, act=act, alpha=alpha, gain=gain, clamp=clamp if clamp >= 0 else None)
+
+
+class _FusedConv(torch.autograd.Function):
+    """cfg = (mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra).
+    mode 'same': y = epilogue(conv(x * styles, w; stride, padding)[:out_hw]);
+    mode 'up2' : y = epilogue(blur(conv_transpose(x * styles, w; stride 2), f, blur_pad, gain 4))."""
+
+    @staticmethod
+    def forward(ctx, x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg):
+        mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
+        x = x.contiguous()
+        co = w.shape[0]
+        ep = dict(noise=noise, noise_gain=noise_strength if noise is not None else None, bias=bias, act=act, alpha=alpha,
+                  gain=gain, clamp=clamp)
+        if mode == 'same':
+            plan = _conv.plan_conv(k, k, stride=stride, padding=padding)
+            y = _conv.conv2d(x, plan.pack(w), plan, co, in_scale=styles, out_scale=dcoefs, out_hw=out_hw, **ep)
+        else:
+            plan = _conv.plan_conv_transpose(k, k, stride=2, padding=0)
+            th, tw = plan.out_size(x.shape[2], x.shape[3])
+            t = _conv.conv2d(x, plan.pack(w), plan, co, in_scale=styles, out_hw=(th, tw + extra))
+            y = _layer.blur_epilogue(t, f, blur_pad, False, 4.0, scale=dcoefs, **ep)
+            ctx.t_shape = t.shape
+        # the output is only needed where the backward reads it: activation slope, clamp mask, demodulation
+        # gradient; a linear, unclamped layer (the residual skips) may then be updated in place by its caller
+        keep_y = act != 'linear' or clamp >= 0 or dcoefs is not None
+        ctx.save_for_backward(x, w, styles, dcoefs, noise, noise_strength, bias, f, y if keep_y else None)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, styles, dcoefs, noise, noise_strength, bias, f, y = ctx.saved_tensors
+        cfg = ctx.cfg
+        mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
+        need = ctx.needs_input_grad   # x, w, styles, dcoefs, noise, noise_strength, bias
+
+        if torch.is_grad_enabled():   # a higher-order graph is wanted: differentiate the composite instead
+            with torch.enable_grad():
+                # Differentiate with respect to aliases of the inputs: an input may be an ancestor of another
+                # (the demodulation coefficients are computed from the styles and the weight), and the gradient
+                # returned for it must hold the direct dependence only - the caller's graph adds the rest.
+                alias = lambda t: t.view_as(t) if t is not None else None
+                ins = [alias(x), alias(w), alias(styles), alias(dcoefs), None, alias(noise_strength), alias(bias)]
+                out = _composite(ins[0], ins[1], ins[2], ins[3], noise, ins[5], ins[6], f, cfg)
+                wanted = [i for i in range(7) if need[i] and ins[i] is not None]
+                grads = torch.autograd.grad(out, [ins[i] for i in wanted], dy, create_graph=True, allow_unused=True)
+            result = [None] * 9
+            for i, g in zip(wanted, grads):
+                result[i] = g
+            return tuple(result)
+
+        ep = dict(scale=dcoefs, noise=noise, noise_gain=noise_strength if noise is not None else None, bias=bias, act=act,
+                  alpha=alpha, gain=gain, clamp=clamp)
+        dz, dbias, ddcoefs, dng = _layer.epilogue_backward(
+            dy, y if y is not None else dy, want_dbias=need[6] and bias is not None, want_dscale=need[3] and dcoefs is not None,
+            want_dnoise_gain=need[5] and noise is not None and noise_strength is not None, **ep)
+        dx = dw = dstyles = None
+        ci = x.shape[1]
+        want_ds = need[2] and styles is not None
+        want_dx = need[0] or want_ds
+        if mode == 'same':
+            if want_dx:
+                plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
+                dx = _conv.conv2d(dz, plan.pack(w, transposed_layout=True), plan, ci, out_scale=styles,
+                                  out_hw=tuple(x.shape[2:]), reduce_x=x if want_ds else None)
+            if need[1]:
+                dw = _conv.conv2d_wgrad(x, dz, k, k, stride=stride, padding=padding, x_scale=styles).to(w.dtype)
+        else:
+            fw, fh = _get_filter_size(f)
+            _, _, th, tw = ctx.t_shape
+            oh, ow = dz.shape[2:]
+            px0, px1, py0, py1 = blur_pad
+            dt = _fir.upfirdn2d(dz, f, 1, 1, 1, 1, fw - px0 - 1, tw - ow + px0, fh - py0 - 1, th - oh + py0, True, 4.0)
+            if want_dx:
+                plan = _conv.plan_conv(k, k, stride=2, padding=0)
+                dx = _conv.conv2d(dt, plan.pack(w.transpose(0, 1)), plan, ci, out_scale=styles, out_hw=tuple(x.shape[2:]),
+                                  reduce_x=x if want_ds else None)
+            if need[1]:   # weight of the transposed conv is w^T [ci, co]; exchange the operands' roles
+                dw = _conv.conv2d_wgrad(dt, x, k, k, stride=2, padding=0, g_scale=styles).transpose(0, 1).to(w.dtype)
+        if want_ds and dx is not None:
+            dx, dstyles = dx
+        if not need[0]:
+            dx = None
+        return (dx, dw, dstyles, ddcoefs, None, dng.reshape(noise_strength.shape) if dng is not None else None,
+                dbias.to(bias.dtype) if dbias is not None else None, None, None)
+
+
+def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=None, dcoefs=None, noise=None,
+               noise_strength=None, bias=None, act='linear', alpha=None, gain=None, clamp=None):
+    """clamp(act(conv2d_resample(x * styles, w, f, up, down, padding) * dcoefs + noise * noise_strength + bias) * gain).
+
+    x [N, I, H, W]; w [O, I, k, k] in x's dtype; styles [N, I] / dcoefs [N, O] float32 or None; noise a
+    float32 plane [H', W'] or [N, 1, H', W'] (unit noise) with its scalar strength; bias [O] in x's dtype.
+    Call `supported()` first.
+    """
+    spec = bias_act.activation_funcs[act]
+    alpha = float(spec.def_alpha if alpha is None else alpha)
+    gain = float(spec.def_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    k = int(w.shape[2])
+    pad = int(padding)
+    styles = styles.to(torch.float32).contiguous() if styles is not None else None
+    dcoefs = dcoefs.to(torch.float32).contiguous() if dcoefs is not None else None
+    noise = _noise_plane(noise, x.dtype)
+    if noise_strength is not None:
+        noise_strength = noise_strength.to(torch.float32)
+    if bias is not None:
+        bias = bias.contiguous()
+    fw, fh = _get_filter_size(f)
+
+    if up == 1 and down == 1:
+        if not flip_weight:
+            w = w.flip([2, 3])
+        out_hw = (x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1)
+        cfg = ('same', k, 1, pad, out_hw, act, alpha, gain, clamp, None, 0)
+    elif down == 2 and up == 1:
+        # resampling filter first (differentiable op of its own), then a strided contraction with the epilogue
+        px0 = pad + (fw - down + 1) // 2
+        px1 = pad + (fw - down) // 2
+        py0 = pad + (fh - down + 1) // 2
+        py1 = pad + (fh - down) // 2
+        if not flip_weight:
+            w = w.flip([2, 3])
+        if k == 1:
+            x = upfirdn2d.upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1])
+            cfg = ('same', 1, 1, 0, tuple(x.shape[2:]), act, alpha, gain, clamp, None, 0)
+        else:
+            out_hw = ((x.shape[2] + py0 + py1 - fh + 1 - k) // down + 1, (x.shape[3] + px0 + px1 - fw + 1 - k) // down + 1)
+            extra = _align_extra(x.shape[3] + px0 + px1 - fw + 1)
+            x = upfirdn2d.upfirdn2d(x, f, padding=[px0, px1 + extra, py0, py1])
+            cfg = ('same', k, down, 0, out_hw, act, alpha, gain, clamp, None, 0)
+    else:   # up == 2, k == 3: transposed convolution (true convolution when flip_weight is False), then blur
+        if flip_weight:
+            w = w.flip([2, 3])
+        px0 = pad + (fw + up - 1) // 2 - (k - 1)
+        px1 = pad + (fw - up) // 2 - (k - up)
+        py0 = pad + (fh + up - 1) // 2 - (k - 1)
+        py1 = pad + (fh - up) // 2 - (k - up)
+        assert max(min(-px0, -px1), 0) == 0 and max(min(-py0, -py1), 0) == 0
+        extra = _align_extra((x.shape[3] - 1) * up + k)
+        cfg = ('up2', k, 2, 0, None, act, alpha, gain, clamp, (px0, px1 - extra, py0, py1), extra)
+    return _FusedConv.apply(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)

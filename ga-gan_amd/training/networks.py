@@ -26,11 +26,17 @@ from ..torch_utils import misc
 from ..torch_utils.ops import bias_act
 from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import fma
+from ..torch_utils.ops import fused_layer
 from ..torch_utils.ops import minibatch_std
 from ..torch_utils.ops import upfirdn2d
 
 # dtype of the blocks the reference runs in float16 (`use_fp16`).
 LOW_PRECISION_DTYPE = torch.bfloat16
+
+
+# Run convolution layers as fused kernels (contraction + demodulation + noise + bias + activation in
+# one pass) where the geometry allows; False = the reference's op-by-op composition.
+FUSE_LAYERS = True
 
 
 def set_low_precision_dtype(dtype):
@@ -310,6 +316,22 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     return x
 
 
+def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding, resample_filter, demodulate,
+                     flip_weight, act, gain, clamp):
+    """Training-path modulated convolution + bias/activation as one fused layer (same arithmetic as
+    `modulated_conv2d(..., fused_modconv=False)` followed by `bias_act`, without the intermediates)."""
+    out_channels, in_channels, kh, kw = weight.shape
+    if x.dtype == torch.float16 and demodulate:   # keep float16 products in range
+        weight = weight * (1 / np.sqrt(in_channels * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    dcoefs = None
+    if demodulate:
+        dcoefs = (styles.square() @ weight.square().sum(dim=[2, 3]).t() + 1e-8).rsqrt()
+    return fused_layer.conv_layer(x, weight.to(x.dtype), f=resample_filter, up=up, padding=padding, flip_weight=flip_weight,
+                                  styles=styles, dcoefs=dcoefs, noise=noise, noise_strength=noise_strength,
+                                  bias=bias, act=act, gain=gain, clamp=clamp)
+
+
 # ----------------------------------------------------------------------------
 
 class FullyConnectedLayer(torch.nn.Module):
@@ -359,11 +381,15 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
-        w = self.weight * self.weight_gain
+        w = (self.weight * self.weight_gain).to(x.dtype)
         b = self.bias.to(x.dtype) if self.bias is not None else None
-        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                            padding=self.padding, flip_weight=(self.up == 1))
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if FUSE_LAYERS and self.activation in ('linear', 'lrelu') and fused_layer.supported(x, w, self.up, self.down):
+            return fused_layer.conv_layer(x, w, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+                                          flip_weight=(self.up == 1), bias=b, act=self.activation,
+                                          gain=self.act_gain * gain, clamp=act_clamp)
+        x = conv2d_resample.conv2d_resample(x=x, w=w, f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
         return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
 
 
@@ -450,6 +476,17 @@ class SynthesisLayer(torch.nn.Module):
         misc.assert_shape(x, [None, self.weight.shape[1], in_resolution, in_resolution])
         styles = w_to_s(self, w=w, weight_gain=1.0, **kwargs)
         weight = weight_to_weight(self, self.weight)
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if (FUSE_LAYERS and not fused_modconv and self.activation in ('linear', 'lrelu')
+                and fused_layer.supported(x, weight.to(x.dtype), self.up, 1)):
+            unit = None
+            if self.use_noise and noise_mode == 'random':
+                unit = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
+            if self.use_noise and noise_mode == 'const':
+                unit = self.noise_const
+            return _modulated_layer(x, weight, styles, unit, self.noise_strength if unit is not None else None,
+                                    self.bias.to(x.dtype), self.up, self.padding, self.resample_filter, True,
+                                    (self.up == 1), self.activation, self.act_gain * gain, act_clamp)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
@@ -458,7 +495,6 @@ class SynthesisLayer(torch.nn.Module):
         x = modulated_conv2d(x=x, weight=weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1),
                              fused_modconv=fused_modconv)
-        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
 
 
@@ -483,6 +519,9 @@ class ToRGBLayer(torch.nn.Module):
     def forward(self, x, w, fused_modconv=True, noise_mode='random', **kwargs):
         styles = w_to_s(self, w=w, weight_gain=self.weight_gain, **kwargs)
         weight = weight_to_weight(self, self.weight)
+        if FUSE_LAYERS and not fused_modconv and fused_layer.supported(x, weight.to(x.dtype), 1, 1):
+            return _modulated_layer(x, weight, styles, None, None, self.bias.to(x.dtype), 1, 0, None, False, True,
+                                    'linear', 1.0, self.conv_clamp)
         x = modulated_conv2d(x=x, weight=weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 

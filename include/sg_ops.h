@@ -73,6 +73,50 @@ typedef struct sg_upfirdn2d_params {
 int sg_upfirdn2d_out_size(int in_size, int up, int pad0, int pad1, int f_size, int down);
 int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream);
 
+/* Layer epilogue applied to a value v produced for sample n, channel c, pixel (oy, ox):
+ *   clamp(act(v * scale[n,c] + noise[n,oy,ox] * *noise_gain + bias[c]) * gain)
+ * scale [n, channels], noise [.., oh, ow] (noise_stride_n elements between samples, 0 = shared) and
+ * *noise_gain are float32; bias [channels] has the dtype of the tensor; any pointer may be NULL.
+ * act: 1 linear, 3 lrelu(alpha); clamp < 0 = off.  It is what the reference applies after a
+ * resampling filter or convolution as separate passes: demodulation and noise
+ * (training/networks.py:647-652) and bias_act (training/networks.py:919-921). */
+typedef struct sg_epilogue {
+    const float* scale;
+    const float* noise;
+    const float* noise_gain;
+    int64_t noise_stride_n;
+    const void* bias;
+    int32_t act;
+    float alpha, gain, clamp;
+} sg_epilogue;
+
+/* upfirdn2d followed by the epilogue in the same pass (up = down = 1, filter up to 4x4, rows
+ * contiguous; other geometries return SG_ERR_UNSUPPORTED).  `ep` may be NULL (= sg_upfirdn2d). */
+int sg_upfirdn2d_epilogue(const sg_upfirdn2d_params* p, const sg_epilogue* ep, sg_stream_t stream);
+
+/* Backward of the epilogue, one pass over dy and y (dense [n, c, hw] of `dtype`):
+ *   g  = dy * gain * act'(.)  (zero where y was clamped; the activation's slope is taken from sign(y))
+ *   dz = g * scale[n,c]                                   -> gradient w.r.t. the pre-epilogue value v
+ *   dbias[c]      += sum_{n,hw} g                          (float atomics; caller zeroes)
+ *   dscale[n,c]    = sum_hw g * v, with v recovered from y: v = (act^-1(y / gain) - noise * *noise_gain - bias[c]) / scale[n,c]
+ *   dnoise_gain[0]+= sum g * noise
+ * No counterpart in the reference's native code: it is the fusion of `bias_act`'s grad=1 kernel
+ * (torch_utils/ops/bias_act.cu:132-142) with the reductions that `fma`'s and `bias_act`'s Python
+ * backward run as separate tensor ops (torch_utils/ops/fma.py:36-45, bias_act.py:211-212). */
+typedef struct sg_epilogue_bwd_params {
+    const void* dy;
+    const void* y;
+    void* dz;
+    sg_epilogue ep;       /* the forward's epilogue */
+    float* dbias;         /* [c] or NULL */
+    float* dscale;        /* [n, c] or NULL (needs ep.scale) */
+    float* dnoise_gain;   /* [1] or NULL (needs ep.noise) */
+    int32_t dtype;
+    int32_t n, c, h, w;
+} sg_epilogue_bwd_params;
+
+int sg_epilogue_backward(const sg_epilogue_bwd_params* p, sg_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * bias_act:  y = clamp(act(x + b[(i / step_b) % size_b]) * gain)  for grad = 0,
  * the first-order backward through the saved output `yref` (or input `xref`
@@ -171,9 +215,19 @@ typedef struct sg_conv2d_params {
     sg_conv2d_phase phase[4];
     int32_t act;
     float alpha, gain, clamp;
+    /* optional reduction of acc[n,co,oy,ox] * reduce_x[n,co,oy,ox] over the pixels, with acc the contraction before
+     * out_scale and the epilogue (reduce_x has y's shape and dtype).  reduce_out is float32 [n, rows, co], zeroed by
+     * the caller, rows = sg_conv2d_reduce_rows(p); the kernel leaves one partial sum per row (no contended atomics)
+     * and the caller adds the rows.  With the data-gradient call this yields the gradient w.r.t. the modulation
+     * styles in the same pass. */
+    const void* reduce_x;
+    float* reduce_out;
 } sg_conv2d_params;
 
 int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
+
+/* Number of partial rows per sample the reduction above writes for this geometry (>= 1), -1 on a bad argument. */
+int sg_conv2d_reduce_rows(const sg_conv2d_params* p);
 
 /* ---------------------------------------------------------------------------
  * conv2d_wgrad: weight gradient of the convolution above (one phase),
