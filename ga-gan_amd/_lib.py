@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsgops.so')
+LIB_PATH = os.environ.get('SG_OPS_LIBRARY') or os.path.join(_HERE, 'libsgops.so')   # override: kernel experiments
 
 SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
            'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad', 'sg_upfirdn2d_epilogue',

@@ -23,6 +23,9 @@
 // on different 16-byte bank slots.  Accumulation is float; the epilogue runs on the
 // accumulators and stores once.
 #include "sg_common.h"
+#include "sg_conv3x3.h"
+
+#include <algorithm>
 
 namespace sg {
 namespace {
@@ -63,6 +66,7 @@ struct Tile {
     int tw_shift, th_shift;
     int lw, lh;           // LDS footprint of one image's tile (pixels)
     int tiles_a, tiles_b, tiles_img;
+    int vec_epi;          // epilogue through LDS with 16-byte global accesses (8 pixels of one channel per lane)
 };
 
 
@@ -305,6 +309,97 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         }
     }
 
+    // ---- epilogue, wide form: the accumulators go through LDS as [pixel][channel] floats and come back as
+    // 8 consecutive pixels of one channel per lane, so that the output (and the reduction operand, and the
+    // noise) move in 16-byte packets and the per-channel constants are fetched once per packet ------------
+    if (t.vec_epi) {
+        constexpr int EP = BM + 4;   // row pitch in floats: the 8 rows of a 16-byte store group fall on all 32 banks
+        __syncthreads();             // every wave has left the multiply loop: its LDS is free
+        float* s_out = reinterpret_cast<float*>(smem) + wave * 64 * EP;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++)
+                *reinterpret_cast<f32x4_t*>(s_out + (j * 16 + lrow) * EP + m * 16 + lgrp * 4) = acc[m][j];
+        __syncthreads();
+        const S noise_gain = (p.noise && p.noise_gain) ? *p.noise_gain : (S)1;
+        S red[M_TILES];
+#pragma unroll
+        for (int m = 0; m < M_TILES; m++) red[m] = 0;
+#pragma unroll
+        for (int it = 0; it < 2 * M_TILES; it++) {
+            const int cblk = it % M_TILES, half = it / M_TILES;
+            const int chl = cblk * 16 + lrow, ch = m0 + chl;
+            const int slot = wave * 64 + half * 32 + lgrp * 8;
+            const int b = b0 + (slot & (t.tw - 1));
+            const int a = a0 + ((slot >> t.tw_shift) & (t.th - 1));
+            const int n = img0 + (slot >> (t.tw_shift + t.th_shift));
+            if (ch >= p.co || a >= AH || b >= AW || n >= p.n) continue;
+            S v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = s_out[(half * 32 + lgrp * 8 + q) * EP + chl];
+            const int64_t off = (((int64_t)n * p.co + ch) * p.oh + a) * p.ow + b;
+            if (p.reduce_out) {
+                S sum = 0;
+                constexpr int PN = Pack<T>::N;
+#pragma unroll
+                for (int h = 0; h < 8 / PN; h++) {
+                    const Pack<T> rx = load_pack((const T*)p.reduce_x + off + h * PN);
+#pragma unroll
+                    for (int q = 0; q < PN; q++) sum += v[h * PN + q] * (S)Elem<T>::load(rx.v[q]);
+                }
+                if (t.imgs == 1) red[cblk] += sum;
+                else if (sum != 0) atomicAdd(p.reduce_out + (int64_t)n * p.co + ch, sum);
+            }
+            const S sc = p.out_scale ? p.out_scale[(int64_t)n * p.co + ch] : (S)1;
+            const S bs = p.bias ? (S)Elem<T>::load(((const T*)p.bias)[ch]) : (S)0;
+            S nz[8];
+            if (p.noise) {
+                const float4* np = reinterpret_cast<const float4*>(p.noise + (int64_t)n * p.noise_stride_n + (int64_t)a * p.ow + b);
+                const float4 n0 = np[0], n1 = np[1];
+                nz[0] = n0.x; nz[1] = n0.y; nz[2] = n0.z; nz[3] = n0.w; nz[4] = n1.x; nz[5] = n1.y; nz[6] = n1.z; nz[7] = n1.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                S x = v[q];
+                if (p.out_scale) x *= sc;
+                if (p.noise) x += nz[q] * noise_gain;
+                if (p.bias) x += bs;
+                if (p.act == 3) x = (x > 0) ? x : x * p.alpha;
+                x *= p.gain;
+                if (p.clamp >= 0) x = fminf(fmaxf(x, -p.clamp), p.clamp);
+                v[q] = x;
+            }
+            constexpr int PN = Pack<T>::N;
+#pragma unroll
+            for (int h = 0; h < 8 / PN; h++) {
+                Pack<T> out;
+#pragma unroll
+                for (int q = 0; q < PN; q++) out.v[q] = Elem<T>::store(v[h * PN + q]);
+                store_pack((T*)p.y + off + h * PN, out);
+            }
+        }
+        if (p.reduce_out && t.imgs == 1) {   // lanes l, l+16, l+32, l+48 hold the same channels; then the four waves
+            __syncthreads();
+            float* s_red = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++) {
+                S r = red[m];
+                r += __shfl_xor(r, 16, 64);
+                r += __shfl_xor(r, 32, 64);
+                if (lgrp == 0) s_red[wave * BM + m * 16 + lrow] = r;
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.co && img0 < p.n) {
+                const float r = s_red[tid] + s_red[BM + tid] + s_red[2 * BM + tid] + s_red[3 * BM + tid];
+                const int rows = t.tiles_a * t.tiles_b * p.num_phases;
+                const int row = (ta * t.tiles_b + tb) * p.num_phases + phase;
+                p.reduce_out[((int64_t)img0 * rows + row) * p.co + m0 + tid] = r;
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: scale, noise, bias, activation, gain, clamp; one store per element ----------
     const S noise_gain = (p.noise && p.noise_gain) ? *p.noise_gain : (S)1;
     T* __restrict__ y = (T*)p.y;
@@ -408,6 +503,7 @@ Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     }
     Tile t;
     t.split_k = 1;
+    t.vec_epi = 0;
     t.tw = 32;
     while (t.tw > 1 && t.tw / 2 >= AW) t.tw /= 2;              // smallest power of two covering AW, at most 32
     int rest = kPixels / t.tw;
@@ -435,14 +531,15 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     const int64_t tiles_px = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img * p.num_phases;
     const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) >= 256) ? 4 : 1;
     const int BM = 16 * m_tiles;
-    const size_t lds = (size_t)t.imgs * t.lh * t.lw * kPitch + (size_t)max_taps * BM * kPitch;
+    size_t lds = (size_t)t.imgs * t.lh * t.lw * kPitch + (size_t)max_taps * BM * kPitch;
     SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
     const int64_t tiles = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img;
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     // Low-resolution float layers: few pixel tiles and a long K loop.  Without an epilogue the sum over input
     // channels can be divided over workgroups that add into a zeroed output.
     t.split_k = 1;
-    const bool plain = !p.in_scale && !p.out_scale && !p.bias && !p.noise && p.act == 1 && p.gain == 1.f && p.clamp < 0;
+    const bool plain = !p.in_scale && !p.out_scale && !p.bias && !p.noise && p.act == 1 && p.gain == 1.f && p.clamp < 0 &&
+                       !p.reduce_out;
     if (sizeof(T) == 4 && plain) {
         constexpr int KCH = kChunkBytes / (int)sizeof(T);
         const int64_t blocks = tiles * ((p.co + BM - 1) / BM) * p.num_phases;
@@ -453,6 +550,11 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
             if (e != hipSuccess) return fail((int)e, "conv2d: cannot zero the output: %s", hipGetErrorString(e));
         }
     }
+    // Wide epilogue: whole 8-pixel packets of a row must be addressable with aligned 16-byte accesses.
+    t.vec_epi = t.split_k == 1 && p.out_step == 1 && p.num_phases == 1 && p.phase[0].oy0 == 0 && p.phase[0].ox0 == 0 &&
+                p.ow % 8 == 0 && t.tw >= 8 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
+                (!p.reduce_out || aligned16(p.reduce_x));
+    if (t.vec_epi) lds = std::max(lds, (size_t)kPixels * (BM + 4) * sizeof(float));
     dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)(p.num_phases * t.split_k));
     auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
     if (lds > 64 * 1024) {   // opt in to large dynamic LDS (idempotent, cheap)
@@ -595,7 +697,7 @@ __global__ void __launch_bounds__(kThreads) conv2d_wgrad_kernel(sg_conv2d_wgrad_
 
 template <class T>
 int launch_wgrad(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
-    Tile t;
+    Tile t{};
     t.tw = 32;
     while (t.tw > 4 && t.tw / 2 >= p.gw) t.tw /= 2;
     int rest = kPixels / t.tw;
@@ -654,6 +756,7 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
                SG_ERR_INVALID_ARGUMENT, "conv2d: tensor is too large");
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->w && p->y, SG_ERR_NULL_POINTER, "conv2d: x, w and y must not be NULL");
+    if (conv3x3_eligible(*p)) return conv3x3_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
         case SG_F32: return launch<float>(*p, (hipStream_t)stream);
         case SG_F16: return launch<__half>(*p, (hipStream_t)stream);

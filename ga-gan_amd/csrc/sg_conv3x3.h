@@ -1,0 +1,26 @@
+// Internal interface between the general convolution entry point and the 3x3 unit-stride kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sg_ops.h"
+
+namespace sg {
+
+struct Conv3x3Args {
+    const void* x; const void* w; void* y;
+    const float* in_scale; const float* out_scale; const void* bias;
+    const float* noise; const float* noise_gain; const void* reduce_x; float* reduce_out;
+    int n, ci, co, h, wid, oh, ow;   // wid: input width
+    int dy0;             // input row of output row a, tap ky: a + dy0 + ky
+    int px_shift;        // pixel column (relative to the tile's first output column) where the staged packets start
+    int px_col;          // column of the footprint's first pixel inside the staged image, 0..7
+    int tiles_a, tiles_b;
+    int noise_stride;
+    float slope, gain, hi;   // leaky-ReLU slope (1: linear), output gain, clamp bound (+inf: none)
+};
+
+bool conv3x3_eligible(const sg_conv2d_params& p);
+int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
+
+}  // namespace sg

@@ -1,0 +1,323 @@
+// 3x3, unit-stride convolution of 16-bit tensors on the matrix cores: the shape that carries
+// nearly all the arithmetic of the StyleGAN2 networks at resolutions of 32 and above (synthesis
+// and discriminator layers, and - with transposed weights - their data gradients).  Same
+// contract as the general kernel of sg_conv2d.hip (modulation on the input, demodulation /
+// noise / bias / leaky ReLU / gain / clamp on the output, optional style-gradient reduction);
+// sg_conv2d dispatches here when the geometry qualifies.
+//
+// What the specialisation buys over the general kernel:
+//   * all loop bounds are constants: the 9 taps x 4 pixel tiles x 4 channel tiles of a chunk are one
+//     straight-line block of 72 LDS reads and 144 MFMAs that the compiler software-pipelines;
+//   * the next chunk's input packets and weights are loaded into registers before the multiply phase
+//     and written to LDS after it, so HBM/L2 latency is hidden behind the MFMAs; during the last
+//     chunk the epilogue's operands (scales, bias, noise, reduction operand) are loaded instead;
+//   * LDS rows are 64 bytes with an XOR swizzle of the 16-byte slots: conflict-free 16-byte reads
+//     without padding;
+//   * pixels are the matrix rows and channels the columns, so a lane ends up with 4 consecutive
+//     pixels of one channel and stores 8 bytes at a time without a transposition.
+//
+// Tile: 64 output channels x (8 x 32) output pixels of one image per workgroup of 4 waves; the K
+// loop walks the input channels 32 at a time.  GEMM view: M = pixels, N = channels, K = 32 x 9.
+#include "sg_common.h"
+#include "sg_conv3x3.h"
+
+namespace sg {
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int TW = 32, TH = 8;            // output pixel tile
+constexpr int KCH = 32;                   // input channels per chunk (64 bytes per pixel)
+constexpr int BM = 64;                    // output channels per workgroup
+constexpr int LH = TH + 2;                // input footprint rows
+constexpr int NV = 6;                     // 8-pixel packets per footprint row (34 pixels at any alignment)
+constexpr int LWP = NV * 8;               // pixels per LDS image row
+constexpr int kRow = 64;                  // bytes per LDS row (one pixel or one output channel, 32 channels)
+constexpr int kInBytes = LH * LWP * kRow; // 30720
+constexpr int kWBytes = 9 * BM * kRow;    // 36864
+constexpr int ROW_STEPS = LH / 2;         // a lane covers every second footprint row: 5 packets of 2 channels
+
+template <class T> struct Mma16;
+template <> struct Mma16<__hip_bfloat16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<__half> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+// Byte offset of (row, byte) in a swizzled image: the 16-byte slot s of row r lives at slot s ^ ((r >> 1) & 3),
+// which spreads the 16 rows a ds_read_b128 lane group touches over all 16 bank slots.
+__device__ __forceinline__ int swz(int row, int byte) {
+    return row * kRow + ((((byte >> 4) ^ (row >> 1)) & 3) << 4) + (byte & 15);
+}
+
+template <class T> __device__ __forceinline__ float lo16(unsigned w) { return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(w & 0xffffu))); }
+template <class T> __device__ __forceinline__ float hi16(unsigned w) { return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(w >> 16))); }
+template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(a)) |
+           ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
+}
+
+template <class T>
+__global__ void __launch_bounds__(kThreads, 2) conv3x3_kernel(Conv3x3Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_in = smem;
+    unsigned char* s_w = smem + kInBytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+
+    // ---- which tile ---------------------------------------------------------------------------------
+    int unit = blockIdx.x;
+    const int tb = unit % g.tiles_b; unit /= g.tiles_b;
+    const int ta = unit % g.tiles_a; unit /= g.tiles_a;
+    const int n = unit % g.n;
+    const int m0 = (unit / g.n) * BM;
+    const int a0 = ta * TH, b0 = tb * TW;
+    const int plane = g.h * g.wid;
+    const T* __restrict__ x = (const T*)g.x + (unsigned)(n * g.ci * plane);   // fewer than 2^31 elements per tensor
+    const T* __restrict__ w = (const T*)g.w;
+
+    // ---- input fetch: lane = (channel pair cg, packet v, row parity); 5 row steps ---------------------
+    const int cg = tid & 15, fv = (tid >> 4) & 7, fpar = tid >> 7;
+    const int px0 = b0 + g.px_shift + fv * 8;                       // first pixel column of this lane's packets
+    const bool col_ok = fv < NV && px0 >= 0 && px0 < g.wid;
+    const int iy_first = a0 + g.dy0 + fpar;
+    uint4 va[ROW_STEPS], vb[ROW_STEPS], vw[9];
+    float s0 = 1.f, s1 = 1.f;
+
+    auto fetch = [&](int c0) {
+        const int c = c0 + 2 * cg;
+        const bool c_ok = col_ok && c < g.ci, two = c + 1 < g.ci;
+        const T* src0 = x + (unsigned)(c * plane + px0);
+#pragma unroll
+        for (int q = 0; q < ROW_STEPS; q++) {
+            const int iy = iy_first + 2 * q;
+            va[q] = make_uint4(0, 0, 0, 0);
+            vb[q] = make_uint4(0, 0, 0, 0);
+            if (c_ok && iy >= 0 && iy < g.h) {
+                const T* src = src0 + iy * g.wid;
+                va[q] = *reinterpret_cast<const uint4*>(src);
+                if (two) vb[q] = *reinterpret_cast<const uint4*>(src + plane);
+            }
+        }
+        if (g.in_scale) {
+            s0 = (c < g.ci) ? g.in_scale[n * g.ci + c] : 0.f;
+            s1 = (c + 1 < g.ci) ? g.in_scale[n * g.ci + c + 1] : 0.f;
+        }
+        // weights [tap][co][ci]: packet e = tid + 256 q is tap q, output channel tid >> 2, 16-byte slot tid & 3
+        const int o = m0 + (tid >> 2), cw = c0 + (tid & 3) * 8;
+        const bool w_ok = o < g.co && cw < g.ci;
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            vw[q] = make_uint4(0, 0, 0, 0);
+            if (w_ok) vw[q] = *reinterpret_cast<const uint4*>(w + (unsigned)((q * g.co + o) * g.ci + cw));
+        }
+    };
+
+    auto commit = [&]() {
+        if (fv < NV) {
+#pragma unroll
+            for (int q = 0; q < ROW_STEPS; q++) {
+                const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
+                const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
+                const int r0 = ((fpar + 2 * q) * NV + fv) * 8;   // a multiple of 8: the swizzle of row r0 + j is that of j
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
+                    unsigned out;
+                    if (g.in_scale) out = pack16<T>(lo16<T>(ea) * s0, lo16<T>(eb) * s1);
+                    else out = (ea & 0xffffu) | (eb << 16);
+                    *reinterpret_cast<unsigned*>(s_in + swz(r0 + j, cg * 4)) = out;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) *reinterpret_cast<uint4*>(s_w + swz(q * BM + (tid >> 2), (tid & 3) * 16)) = vw[q];
+    };
+
+    // ---- multiply-phase addressing ----------------------------------------------------------------------
+    // n-tile j of wave w: output row 2w + (j >> 1), columns 16 (j & 1) .. +15; lane l addresses pixel column l & 15
+    int brow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * LWP + (j & 1) * 16 + lrow + g.px_col;
+    const int a_lane = lrow * kRow + (((lgrp ^ (lrow >> 1)) & 3) << 4);
+
+    f32x4_t acc[4][4];   // [channel tile m][pixel tile j]: rows = pixels 4 lgrp + r, column = channel lrow
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue operands, loaded during the last multiply phase -----------------------------------------
+    float sc[4], bs[4];
+    float4 nz[4];
+    uint2 rx[4][4];
+    const int ch0 = m0 + lrow;
+    const int ch_stride = 16 * g.oh * g.ow;
+    unsigned off0[4];
+    bool inside[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int a = a0 + 2 * wave + (j >> 1), b = b0 + (j & 1) * 16 + 4 * lgrp;
+        inside[j] = a < g.oh && b < g.ow;
+        off0[j] = (unsigned)(((n * g.co + ch0) * g.oh + a) * g.ow + b);
+    }
+    auto fetch_epilogue = [&]() {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int ch = min(ch0 + 16 * m, g.co - 1);
+            sc[m] = g.out_scale ? g.out_scale[n * g.co + ch] : 1.f;
+            bs[m] = g.bias ? Elem<T>::load(((const T*)g.bias)[ch]) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            nz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.noise && inside[j]) {
+                const int a = a0 + 2 * wave + (j >> 1), b = b0 + (j & 1) * 16 + 4 * lgrp;
+                nz[j] = *reinterpret_cast<const float4*>(g.noise + n * g.noise_stride + a * g.ow + b);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                rx[j][m] = make_uint2(0, 0);
+                if (g.reduce_out && inside[j] && ch0 + 16 * m < g.co)
+                    rx[j][m] = *reinterpret_cast<const uint2*>((const T*)g.reduce_x + off0[j] + m * ch_stride);
+            }
+        }
+    };
+
+    // ---- K loop ---------------------------------------------------------------------------------------------
+    // 9 taps per chunk; the fragments of tap t + 1 are read while the MFMAs of tap t run (two register sets).
+    auto read_tap = [&](int tap, uint4 (&a)[4], uint4 (&b)[4]) {
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const uint4*>(s_w + (tap * BM + m * 16) * kRow + a_lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = brow[j] + ky * LWP + kx;
+            b[j] = *reinterpret_cast<const uint4*>(s_in + row * kRow + (((lgrp ^ (row >> 1)) & 3) << 4));
+        }
+    };
+    auto multiply = [&]() {
+        uint4 fa[2][4], fb[2][4];
+        read_tap(0, fa[0], fb[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            if (tap + 1 < 9) read_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int m = 0; m < 4; m++) Mma16<T>::run(fb[tap & 1][j], fa[tap & 1][m], acc[m][j]);   // rows: pixels, columns: channels
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    fetch(0);
+    const int c_last = ((g.ci - 1) / KCH) * KCH;
+    for (int c0 = 0; c0 < c_last; c0 += KCH) {
+        __syncthreads();   // everyone is done reading the previous chunk
+        commit();
+        __syncthreads();
+        fetch(c0 + KCH);   // in flight during the multiply phase
+        multiply();
+    }
+    __syncthreads();
+    commit();
+    __syncthreads();
+    fetch_epilogue();      // the last chunk's multiply phase covers the epilogue's loads instead
+    multiply();
+
+    // ---- epilogue: straight-line arithmetic (scale 1, noise 0, bias 0, slope 1, clamp +-inf are no-ops) -------
+    const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
+    float red[4] = {0.f, 0.f, 0.f, 0.f};
+    T* __restrict__ y = (T*)g.y;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float nzj[4] = {nz[j].x * noise_gain, nz[j].y * noise_gain, nz[j].z * noise_gain, nz[j].w * noise_gain};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if (!inside[j] || ch0 + 16 * m >= g.co) continue;
+            float v[4] = {acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
+            red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float e = v[r] * sc[m] + nzj[r] + bs[m];
+                e = (e > 0.f) ? e : e * g.slope;
+                v[r] = fminf(fmaxf(e * g.gain, -g.hi), g.hi);
+            }
+            *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = make_uint2(pack16<T>(v[0], v[1]), pack16<T>(v[2], v[3]));
+        }
+    }
+    if (g.reduce_out) {
+        // lanes l, l+16, l+32, l+48 share their channels; then the four waves through LDS; one partial row per tile
+        __syncthreads();   // every wave has left the multiply loop; LDS can be reused
+        float* s_red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            float r = red[m];
+            r += __shfl_xor(r, 16, 64);
+            r += __shfl_xor(r, 32, 64);
+            if (lgrp == 0) s_red[wave * BM + m * 16 + lrow] = r;
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.co) {
+            const float r = s_red[tid] + s_red[BM + tid] + s_red[2 * BM + tid] + s_red[3 * BM + tid];
+            g.reduce_out[((n * g.tiles_a + ta) * g.tiles_b + tb) * g.co + m0 + tid] = r;
+        }
+    }
+}
+
+}  // namespace
+
+bool conv3x3_eligible(const sg_conv2d_params& p) {
+    if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
+    if (p.num_phases != 1 || p.in_step != 1 || p.out_step != 1) return false;
+    const sg_conv2d_phase& ph = p.phase[0];
+    if (ph.nky != 3 || ph.nkx != 3 || ph.oy0 != 0 || ph.ox0 != 0 || ph.w_offset != 0) return false;
+    if (p.ow < TW || p.oh < 5) return false;                      // the general kernel would pick the same 8 x 32 tile
+    if (p.w_in % 8 != 0 || p.ow % 4 != 0 || p.ci % 8 != 0) return false;
+    if (p.ci <= 2 * KCH) return false;   // one or two chunks: nothing to overlap the loads with; the general kernel's finer
+                                         // scheduling (more independent workgroup phases) is faster there (measured)
+    if (!aligned16(p.x) || !aligned16(p.w)) return false;
+    const auto aligned8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
+    if (!aligned8(p.y) || (p.reduce_out && !aligned8(p.reduce_x))) return false;
+    if (p.noise && (!aligned16(p.noise) || p.noise_stride_n % 4 != 0)) return false;
+    return true;
+}
+
+int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
+    Conv3x3Args g;
+    g.x = p.x; g.w = p.w; g.y = p.y;
+    g.in_scale = p.in_scale; g.out_scale = p.out_scale; g.bias = p.bias;
+    g.noise = p.noise; g.noise_gain = p.noise_gain; g.reduce_x = p.reduce_x; g.reduce_out = p.reduce_out;
+    g.n = p.n; g.ci = p.ci; g.co = p.co; g.h = p.h; g.wid = p.w_in; g.oh = p.oh; g.ow = p.ow;
+    g.dy0 = p.phase[0].dy0;
+    // input column of output column b, tap kx: b + dx0 + kx.  Packets start at the multiple of 8 at or below b0 + dx0.
+    const int dx0 = p.phase[0].dx0;
+    const int fl = (dx0 >= 0) ? dx0 / 8 : -((-dx0 + 7) / 8);
+    g.px_shift = fl * 8;            // first packet's pixel column relative to b0
+    g.px_col = dx0 - g.px_shift;    // column of the footprint's first pixel inside the LDS image, 0..7
+    g.tiles_a = (p.oh + TH - 1) / TH;
+    g.tiles_b = (p.ow + TW - 1) / TW;
+    g.noise_stride = (int)p.noise_stride_n;
+    g.slope = (p.act == 3) ? p.alpha : 1.f;
+    g.gain = p.gain;
+    g.hi = (p.clamp >= 0.f) ? p.clamp : __builtin_inff();
+    const int64_t units = (int64_t)g.tiles_a * g.tiles_b * p.n * ((p.co + BM - 1) / BM);
+    SG_REQUIRE(units <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
+    constexpr size_t lds = kInBytes + kWBytes;
+    auto kernel = (p.dtype == SG_BF16) ? conv3x3_kernel<__hip_bfloat16> : conv3x3_kernel<__half>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kThreads), lds, stream, g);
+    return check_launch("sg_conv2d");
+}
+
+}  // namespace sg

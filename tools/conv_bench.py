@@ -15,6 +15,8 @@ LAYERS = [  # ci, co, h, dtype, kind
     (64, 3, 256, torch.bfloat16, '1x1'), (3, 64, 256, torch.bfloat16, '1x1'),
     (64, 128, 257, torch.bfloat16, 'down'),
 ]
+if os.environ.get('ONLY'):
+    LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
 if os.environ.get('BIG'):
     LAYERS = [(32, 32, 1024, torch.bfloat16, 'conv'), (64, 64, 512, torch.bfloat16, 'conv'), (64, 32, 512, torch.bfloat16, 'up')]
 
@@ -56,6 +58,8 @@ for ci, co, h, dtype, kind in LAYERS:
         taps = 9 / 4
     ours = lambda: cp.conv2d(x, packed, plan, co)
     y = ours()
+    if os.environ.get('NOLIB'):
+        lib = ours
     t0 = time.time(); lib(); torch.cuda.synchronize(); first = time.time() - t0
     t_ours, t_lib = timeit(ours), timeit(lib)
     oh = y.shape[2]
