@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graphs', action='store_true',
+                    help='record the forward/backward of every phase into a HIP graph at the first step and replay it '
+                         'afterwards (same speed on one GPU, where the step is GPU-bound; spares the host)')
     return ap.parse_args()
 
 
@@ -52,7 +55,7 @@ def make_trainer(args, rank, world):
     opts = training_loop.setup_training_options(cfg=cfg, resolution=res, batch_size=batch_gpu * world, num_gpus=world,
                                                 batch_gpu=batch_gpu, glrate=0.02 if par != 'FULL' else None,
                                                 **getattr(training_loop, par))
-    return training_loop.Trainer(rank=rank, random_seed=0, **opts), desc, res, batch_gpu
+    return training_loop.Trainer(rank=rank, random_seed=0, use_graphs=bool(getattr(args, 'graphs', False)), **opts), desc, res, batch_gpu
 
 
 def kernel_roofline(trainer, real, real_c, steps):
@@ -62,10 +65,12 @@ def kernel_roofline(trainer, real, real_c, steps):
     (algorithmic flops per launch / average launch time), for the streaming kernels against HBM
     (algorithmic bytes per launch = operands read once + result written once)."""
     from ga_gan_amd import _lib
+    graphs, trainer.use_graphs = trainer.use_graphs, False   # events are recorded around host launches
     _lib.profile_begin()
     for _ in range(steps):
         trainer.step(real, real_c)
     records = _lib.profile_end()
+    trainer.use_graphs = graphs
     if not records:
         return None, {}
     by_kernel = {}
@@ -206,7 +211,7 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
                    config=dict(workload=desc, resolution=res, global_batch=global_batch, per_gpu_batch=batch_gpu,
-                               parallelism=f'dp{world}', iteration='Gmain+Dmain every step, Greg every 4th, Dreg every 16th',
+                               parallelism=f'dp{world}', hip_graphs=bool(trainer.use_graphs), iteration='Gmain+Dmain every step, Greg every 4th, Dreg every 16th',
                                kernels='conv2d / conv2d_wgrad (MFMA), upfirdn2d, bias_act, minibatch-std: hand-written HIP; small GEMMs: torch'),
                    roofline=roofline, cpu_baseline=baseline, kernels=kernels,
                    grad_exchange_bytes_per_step=int(trainer.exchanged_bytes / max(trainer.batch_idx, 1)))

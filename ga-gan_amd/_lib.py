@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('SG_OPS_LIBRARY') or os.path.join(_HERE, 'libsgops.so'
 
 SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
            'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad', 'sg_upfirdn2d_epilogue',
-           'sg_epilogue_backward', 'sg_conv2d_reduce_rows')
+           'sg_epilogue_backward', 'sg_conv2d_reduce_rows', 'sg_conv2d_kernel', 'sg_conv2d_wgrad_kernel')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -72,6 +72,10 @@ def lib():
             getattr(handle, name).restype = ctypes.c_int
         handle.sg_conv2d_reduce_rows.argtypes = [vp]
         handle.sg_conv2d_reduce_rows.restype = ctypes.c_int
+        handle.sg_conv2d_kernel.argtypes = [vp]
+        handle.sg_conv2d_kernel.restype = ctypes.c_char_p
+        handle.sg_conv2d_wgrad_kernel.argtypes = [vp]
+        handle.sg_conv2d_wgrad_kernel.restype = ctypes.c_char_p
         _lib = handle
     return _lib
 
@@ -106,6 +110,11 @@ def profile_begin():
     The events are recorded on the stream the kernel is enqueued on."""
     global _profile
     _profile = []
+
+
+def profiling():
+    """True while launches are being recorded."""
+    return _profile is not None
 
 
 def profile_end():

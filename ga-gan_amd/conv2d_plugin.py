@@ -3,6 +3,7 @@ cores with optional per-sample input / output scales, noise, bias, leaky-ReLU, g
 clamp fused in.  A `Plan` describes the geometry (plain, strided or transposed in
 polyphase form) and how the weight tensor is packed for it."""
 import ctypes
+import os
 
 import torch
 
@@ -44,10 +45,28 @@ class Plan:
             w = w.transpose(0, 1)
         parts = []
         for (_, _, _, _, nky, nkx, ky_idx, kx_idx) in self.phases:
-            sel = w[:, :, ky_idx][:, :, :, kx_idx] if (list(ky_idx) != list(range(self.kh)) or
-                                                        list(kx_idx) != list(range(self.kw))) else w
+            sel, flips = w, []
+            for dim, idx in ((2, ky_idx), (3, kx_idx)):
+                sel, flipped = _take(sel, dim, list(idx))
+                if flipped:
+                    flips.append(dim)
+            if flips:
+                sel = sel.flip(flips)
             parts.append(sel.permute(2, 3, 0, 1).reshape(-1))
         return torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
+
+
+def _take(w, dim, idx):
+    """w indexed along `dim` by the arithmetic progression `idx`, as a view: (tensor, needs_flip).  Views and one
+    flip kernel instead of an index tensor keep the call free of host-to-device copies (graph capture)."""
+    if len(idx) == 1:
+        return w.narrow(dim, idx[0], 1), False
+    step = idx[1] - idx[0]
+    assert step != 0 and all(b - a == step for a, b in zip(idx, idx[1:])), idx
+    lo, hi = min(idx), max(idx)
+    index = [slice(None)] * w.dim()
+    index[dim] = slice(lo, hi + 1, abs(step))
+    return w[tuple(index)], step < 0
 
 
 def plan_conv(kh, kw, stride=1, padding=0):
@@ -83,6 +102,7 @@ def plan_conv_transpose(kh, kw, stride=2, padding=0):
 
 
 ACT_INDEX = {'linear': 1, 'lrelu': 3}
+_DETAIL = bool(os.environ.get('SG_PROFILE_DETAIL'))   # profiling labels carry the geometry
 _DTYPE_NAME = {torch.float32: 'float', torch.float16: '__half', torch.bfloat16: '__hip_bfloat16'}
 
 
@@ -143,7 +163,9 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
         partial = torch.zeros([n, rows, co], dtype=torch.float32, device=x.device)
         p.reduce_out = _lib.ptr(partial)
     taps = sum(ph[4] * ph[5] for ph in plan.phases)
-    label = f'conv2d_mfma_kernel<{_DTYPE_NAME[x.dtype]}>'
+    label = f'{_lib.lib().sg_conv2d_kernel(ctypes.byref(p)).decode()}<{_DTYPE_NAME[x.dtype]}>' if _lib.profiling() else ''
+    if _DETAIL and label:
+        label += f' {plan.kind} k{plan.kh} {ci}->{co} out{oh}x{ow} step{plan.in_step}/{plan.out_step} n{n}'
     _lib.launch('sg_conv2d', p, x, label, _lib.nbytes(x, y, reduce_x), flops=2.0 * n * co * ci * taps * (oh * ow) / len(plan.phases))
     if reduce_x is not None:
         return y, (partial.sum(dim=1) if partial.shape[1] > 1 else partial[:, 0])
@@ -179,6 +201,12 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None):
         p = Conv2dWgradParams(x=_lib.ptr(x), g=_lib.ptr(g), dw=_lib.ptr(dw), x_scale=_lib.ptr(x_scale),
                               g_scale=_lib.ptr(g_scale), dtype=_lib.dtype_code(x), n=n, cx=cx, h=h, w_in=w, cg=cg,
                               gh=gh, gw=gw, step=stride, dy0=-padding, dx0=-padding, nky=kh, nkx=kw)
-        label = f'conv2d_wgrad_kernel<{_DTYPE_NAME[x.dtype]},{1 if kh * kw <= 1 else 4 if kh * kw <= 4 else 9}>'
+        label = ''
+        if _lib.profiling():
+            name = _lib.lib().sg_conv2d_wgrad_kernel(ctypes.byref(p)).decode()
+            taps = '' if name == 'wgrad3x3_kernel' else f',{1 if kh * kw <= 1 else 4 if kh * kw <= 4 else 9}'
+            label = f'{name}<{_DTYPE_NAME[x.dtype]}{taps}>'
+        if _DETAIL and label:
+            label += f' k{kh} {cx}->{cg} g{gh}x{gw} step{stride} n{n}'
         _lib.launch('sg_conv2d_wgrad', p, x, label, _lib.nbytes(x, g), flops=2.0 * n * cg * cx * kh * kw * gh * gw)
     return dw.permute(2, 3, 0, 1)

@@ -19,6 +19,9 @@ constexpr int kWave = 64;  // CDNA wavefront
 char* error_slot();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+// Opt a kernel in to 160 KB of dynamic LDS, once per kernel and device (not a stream operation: kept out of the
+// launch path proper so that launches can be captured into graphs).  Returns hipSuccess or the error.
+hipError_t allow_large_lds(const void* kernel);
 
 #define SG_REQUIRE(cond, code, ...)                      \
     do {                                                 \

@@ -484,6 +484,10 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     }
 }
 
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ dst, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) dst[i] = 0u;
+}
+
 int ilog2(int v) {
     int s = 0;
     while ((1 << s) < v) s++;
@@ -546,8 +550,12 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
         const int chunks = (p.ci + KCH - 1) / KCH;
         while (t.split_k < 8 && blocks * t.split_k < 512 && chunks / (t.split_k * 2) >= 4) t.split_k *= 2;
         if (t.split_k > 1) {
-            hipError_t e = hipMemsetAsync(p.y, 0, (size_t)p.n * p.co * p.oh * p.ow * sizeof(T), stream);
-            if (e != hipSuccess) return fail((int)e, "conv2d: cannot zero the output: %s", hipGetErrorString(e));
+            // (a kernel rather than hipMemsetAsync: memset nodes recorded into a HIP graph were seen to act on
+            // the first replay only)
+            const size_t words = (size_t)p.n * p.co * p.oh * p.ow * sizeof(T) / 4;
+            const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 4096);
+            hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned*)p.y, words);
+            if (int rc = check_launch("sg_conv2d (zero)")) return rc;
         }
     }
     // Wide epilogue: whole 8-pixel packets of a row must be addressable with aligned 16-byte accesses.
@@ -558,7 +566,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)(p.num_phases * t.split_k));
     auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
     if (lds > 64 * 1024) {   // opt in to large dynamic LDS (idempotent, cheap)
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_large_lds((const void*)kernel);
         if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, p, t);
@@ -726,7 +734,7 @@ int launch_wgrad(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
     dim3 grid((unsigned)split, (unsigned)chunks_g, (unsigned)chunks_x);
     auto kernel = (taps <= 1) ? conv2d_wgrad_kernel<T, 1> : (taps <= 4) ? conv2d_wgrad_kernel<T, 4> : conv2d_wgrad_kernel<T, 9>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_large_lds((const void*)kernel);
         if (e != hipSuccess) return fail((int)e, "conv2d_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, p, t, (int)tiles);
@@ -777,6 +785,7 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
                SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: tensor is too large");
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->g && p->dw, SG_ERR_NULL_POINTER, "conv2d_wgrad: x, g and dw must not be NULL");
+    if (wgrad3x3_eligible(*p)) return wgrad3x3_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
         case SG_F32: return launch_wgrad<float>(*p, (hipStream_t)stream);
         case SG_F16: return launch_wgrad<__half>(*p, (hipStream_t)stream);
@@ -790,4 +799,14 @@ extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
     int taps = 0;
     const sg::Tile t = sg::make_tile(*p, &taps);
     return (t.imgs == 1) ? t.tiles_a * t.tiles_b * p->num_phases : 1;
+}
+
+extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
+    if (p == nullptr) return "";
+    return sg::conv3x3_eligible(*p) ? "conv3x3_kernel" : "conv2d_mfma_kernel";
+}
+
+extern "C" const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p) {
+    if (p == nullptr) return "";
+    return sg::wgrad3x3_eligible(*p) ? "wgrad3x3_kernel" : "conv2d_wgrad_kernel";
 }

@@ -1,4 +1,4 @@
-// Internal interface between the general convolution entry point and the 3x3 unit-stride kernel.
+// Internal interface between the general convolution entry points and the 3x3 unit-stride kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,5 +22,9 @@ struct Conv3x3Args {
 
 bool conv3x3_eligible(const sg_conv2d_params& p);
 int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
+
+// Weight gradient of the same geometry (sg_wgrad3x3.hip); sg_conv2d_wgrad dispatches.
+bool wgrad3x3_eligible(const sg_conv2d_wgrad_params& p);
+int wgrad3x3_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
 
 }  // namespace sg

@@ -314,7 +314,7 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     SG_REQUIRE(units <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     constexpr size_t lds = kInBytes + kWBytes;
     auto kernel = (p.dtype == SG_BF16) ? conv3x3_kernel<__hip_bfloat16> : conv3x3_kernel<__half>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kThreads), lds, stream, g);
     return check_launch("sg_conv2d");

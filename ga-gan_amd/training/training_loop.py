@@ -185,7 +185,7 @@ class Trainer:
 
     def __init__(self, G_kwargs, D_kwargs, G_opt_kwargs, D_opt_kwargs, loss_kwargs=None, batch_size=32, batch_gpu=32,
                  num_gpus=1, rank=0, ema_kimg=10, ema_rampup=None, G_reg_interval=4, D_reg_interval=16,
-                 requires_grad_parts=None, device=None, random_seed=0, augment_pipe=None, resume=None):
+                 requires_grad_parts=None, device=None, random_seed=0, augment_pipe=None, resume=None, use_graphs=False):
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.rank, self.num_gpus = rank, num_gpus
         self.batch_size, self.batch_gpu = batch_size, batch_gpu
@@ -232,6 +232,10 @@ class Trainer:
         self.cur_nimg = 0
         self.batch_idx = 0
         self.exchanged_bytes = 0
+        # HIP graphs: the forward/backward of a phase is recorded once (after its first eager run) and replayed
+        # afterwards, which removes the launch cost of its few thousand small kernels from the host.
+        self.use_graphs = bool(use_graphs)
+        self._graphs = {}
 
     # -- data ------------------------------------------------------------------
     def synthetic_batch(self, generator=None):
@@ -241,6 +245,35 @@ class Trainer:
         img = torch.randint(0, 256, [n, self.G.img_channels, res, res], dtype=torch.uint8, device=self.device,
                             generator=generator)
         return img, torch.zeros([n, self.G.c_dim], device=self.device)
+
+    # -- HIP graphs ---------------------------------------------------------------
+    def _capture_phase(self, phase, r_img, r_c, g_z, g_c):
+        """Record the forward/backward of `phase` on static copies of its inputs.  Nothing executes during the
+        recording; the gradients it produces live in the graph's memory pool and are handed to the parameters
+        after every replay."""
+        static = dict(r_img=r_img.clone(), r_c=r_c.clone(), g_z=g_z.clone(), g_c=g_c.clone())
+        phase.opt.zero_grad(set_to_none=True)
+        set_requires_grad(phase.module, parts=self.requires_grad_parts[phase.name])
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):   # a memory pool of its own: the gradients it holds outlive every replay
+            self.loss.accumulate_gradients(phase=phase.name, real_img=static['r_img'], real_c=static['r_c'],
+                                           gen_z=static['g_z'], gen_c=static['g_c'], sync=True, gain=phase.interval)
+        grads = [(p, p.grad) for p in phase.module.parameters() if p.grad is not None]
+        phase.module.requires_grad_(False)
+        phase.opt.zero_grad(set_to_none=True)
+        self._graphs[phase.name] = (graph, static, grads)
+
+    def _replay_phase(self, phase, r_img, r_c, g_z, g_c):
+        graph, static, grads = self._graphs[phase.name]
+        static['r_img'].copy_(r_img)
+        static['r_c'].copy_(r_c)
+        static['g_z'].copy_(g_z)
+        static['g_c'].copy_(g_c)
+        phase.opt.zero_grad(set_to_none=True)
+        graph.replay()
+        for p, g in grads:
+            p.grad = g
 
     # -- one iteration ----------------------------------------------------------
     def step(self, real_img, real_c, gen_z=None):
@@ -261,12 +294,16 @@ class Trainer:
         for phase, phase_gen_z, phase_gen_c in zip(self.phases, all_gen_z, all_gen_c):
             if self.batch_idx % phase.interval != 0:
                 continue
-            phase.opt.zero_grad(set_to_none=True)
-            set_requires_grad(phase.module, parts=self.requires_grad_parts[phase.name])
-            for round_idx, (r_img, r_c, g_z, g_c) in enumerate(zip(phase_real_img, phase_real_c, phase_gen_z, phase_gen_c)):
-                self.loss.accumulate_gradients(phase=phase.name, real_img=r_img, real_c=r_c, gen_z=g_z, gen_c=g_c,
-                                               sync=(round_idx == rounds - 1), gain=phase.interval)
-            phase.module.requires_grad_(False)
+            graphed = self.use_graphs and rounds == 1 and self._graphs.get(phase.name)
+            if graphed:
+                self._replay_phase(phase, phase_real_img[0], phase_real_c[0], phase_gen_z[0], phase_gen_c[0])
+            else:
+                phase.opt.zero_grad(set_to_none=True)
+                set_requires_grad(phase.module, parts=self.requires_grad_parts[phase.name])
+                for round_idx, (r_img, r_c, g_z, g_c) in enumerate(zip(phase_real_img, phase_real_c, phase_gen_z, phase_gen_c)):
+                    self.loss.accumulate_gradients(phase=phase.name, real_img=r_img, real_c=r_c, gen_z=g_z, gen_c=g_c,
+                                                   sync=(round_idx == rounds - 1), gain=phase.interval)
+                phase.module.requires_grad_(False)
             with torch.autograd.profiler.record_function(phase.name + '_opt'):
                 params = [p for p in phase.module.parameters() if p.grad is not None]
                 self.exchanged_bytes += self.reducer(params)
@@ -275,6 +312,8 @@ class Trainer:
                     for g in grads:
                         misc.nan_to_num_(g)
                     phase.opt.step()
+            if self.use_graphs and rounds == 1 and phase.name not in self._graphs and params:   # (a phase that does nothing is not recorded)
+                self._capture_phase(phase, phase_real_img[0], phase_real_c[0], phase_gen_z[0], phase_gen_c[0])
 
         with torch.autograd.profiler.record_function('Gema'):
             ema_nimg = self.ema_kimg * 1000

@@ -50,6 +50,9 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
         out_stride_w=y.stride(3), out_stride_h=y.stride(2), out_stride_c=y.stride(1), out_stride_n=y.stride(0))
     tiled = (x.stride(3) == 1 and y.stride(3) == 1 and x.dtype != torch.float64 and f.shape[0] <= 4 and f.shape[1] <= 4
              and (upx, upy, downx, downy) in ((1, 1, 1, 1), (2, 2, 1, 1), (1, 1, 2, 2)))
-    label = f'upfirdn2d_tiled_kernel<up{upx} down{downx}>' if tiled else 'upfirdn2d_generic_kernel'
+    if tiled and upx == upy == downx == downy == 1:
+        label = 'upfirdn2d_blur4_kernel'
+    else:
+        label = f'upfirdn2d_tiled_kernel<up{upx} down{downx}>' if tiled else 'upfirdn2d_generic_kernel'
     _lib.launch('sg_upfirdn2d', p, x, label, _lib.nbytes(x, y))
     return y

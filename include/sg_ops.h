@@ -229,6 +229,11 @@ int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
 /* Number of partial rows per sample the reduction above writes for this geometry (>= 1), -1 on a bad argument. */
 int sg_conv2d_reduce_rows(const sg_conv2d_params* p);
 
+/* Name of the device kernel sg_conv2d runs for this geometry (the symbol a profiler reports, without template
+ * arguments): "conv3x3_kernel" for 16-bit 3x3 unit-stride convolutions of more than 64 input channels whose rows
+ * are whole aligned packets, "conv2d_mfma_kernel" otherwise.  Static storage. */
+const char* sg_conv2d_kernel(const sg_conv2d_params* p);
+
 /* ---------------------------------------------------------------------------
  * conv2d_wgrad: weight gradient of the convolution above (one phase),
  *   dw[ky][kx][cg][cx] += sum_{n,a,b} g[n,cg,a,b] * g_scale[n,cg]
@@ -254,6 +259,11 @@ typedef struct sg_conv2d_wgrad_params {
 } sg_conv2d_wgrad_params;
 
 int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stream);
+
+/* Name of the device kernel sg_conv2d_wgrad runs for this geometry: "wgrad3x3_kernel" (16-bit, 3x3, unit stride,
+ * at least 32 channels on both sides, rows of whole packets, gradient planes of 8 x 32 pixels or more) or
+ * "conv2d_wgrad_kernel".  Static storage. */
+const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,8 @@ CASES = [  # name, n, ci, co, h, w, k, kind, stride, padding
     ('3x3_big', 2, 64, 64, 64, 64, 3, 'conv', 1, 1),
     ('3x3_ragged', 3, 40, 72, 19, 23, 3, 'conv', 1, 1),
     ('3x3_lowres', 5, 64, 128, 4, 4, 3, 'conv', 1, 1),
+    ('3x3_wide', 2, 96, 80, 40, 40, 3, 'conv', 1, 1),          # the 3x3 unit-stride kernel, ragged channels and tiles
+    ('3x3_wide_rect', 3, 72, 136, 36, 64, 3, 'conv', 1, 1),
     ('3x3_8x8', 9, 32, 64, 8, 8, 3, 'conv', 1, 1),
     ('1x1_torgb', 3, 64, 3, 32, 32, 1, 'conv', 1, 0),
     ('1x1_fromrgb', 3, 3, 64, 32, 32, 1, 'conv', 1, 0),
@@ -129,6 +131,7 @@ WGRAD_CASES = [  # name, n, ci, co, h, w, k, stride, padding
     ('3x3_same', 3, 32, 64, 16, 16, 3, 1, 1),
     ('3x3_big', 4, 64, 64, 64, 64, 3, 1, 1),
     ('3x3_ragged', 3, 40, 72, 19, 23, 3, 1, 1),
+    ('3x3_wide_ragged', 3, 40, 72, 36, 48, 3, 1, 1),           # the 3x3 unit-stride weight-gradient kernel
     ('3x3_lowres', 8, 64, 96, 4, 4, 3, 1, 1),
     ('1x1', 3, 64, 3, 32, 32, 1, 1, 0),
     ('1x1_fromrgb', 3, 3, 64, 32, 32, 1, 1, 0),

@@ -33,6 +33,8 @@ CASES = [
     (2, 16, 24, 32, 1, 1, 2, False, False, 'linear', None),    # discriminator skip
     (2, 3, 16, 32, 1, 1, 1, False, False, 'lrelu', 0.5),       # from-RGB, clamp active
     (5, 20, 72, 8, 3, 1, 1, True, True, 'lrelu', None),        # ragged channel counts
+    (2, 96, 80, 32, 3, 1, 1, True, True, 'lrelu', 256.0),      # wide layer: the 3x3 unit-stride kernels, forward and both gradients
+    (2, 72, 136, 40, 3, 1, 1, True, False, 'linear', None),
 ]
 
 
