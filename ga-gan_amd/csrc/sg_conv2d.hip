@@ -796,6 +796,7 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
 
 extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
     if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return -1;
+    if (sg::conv3x3_eligible(*p)) return sg::conv3x3_reduce_rows(*p);
     int taps = 0;
     const sg::Tile t = sg::make_tile(*p, &taps);
     return (t.imgs == 1) ? t.tiles_a * t.tiles_b * p->num_phases : 1;

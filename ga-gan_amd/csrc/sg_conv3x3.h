@@ -13,7 +13,7 @@ struct Conv3x3Args {
     const float* noise; const float* noise_gain; const void* reduce_x; float* reduce_out;
     int n, ci, co, h, wid, oh, ow;   // wid: input width
     int dy0;             // input row of output row a, tap ky: a + dy0 + ky
-    int px_shift;        // pixel column (relative to the tile's first output column) where the staged packets start
+    int px_shift;        // pixel column (relative to the tile's first input column b0 * step) where the staged packets start
     int px_col;          // column of the footprint's first pixel inside the staged image, 0..7
     int tiles_a, tiles_b;
     int noise_stride;
@@ -22,6 +22,7 @@ struct Conv3x3Args {
 
 bool conv3x3_eligible(const sg_conv2d_params& p);
 int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
+int conv3x3_reduce_rows(const sg_conv2d_params& p);   // partial rows per sample of the reduction, for eligible geometries
 
 // Weight gradient of the same geometry (sg_wgrad3x3.hip); sg_conv2d_wgrad dispatches.
 bool wgrad3x3_eligible(const sg_conv2d_wgrad_params& p);

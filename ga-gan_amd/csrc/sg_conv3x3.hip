@@ -32,13 +32,20 @@ constexpr int kThreads = 256;
 constexpr int TW = 32, TH = 8;            // output pixel tile
 constexpr int KCH = 32;                   // input channels per chunk (64 bytes per pixel)
 constexpr int BM = 64;                    // output channels per workgroup
-constexpr int LH = TH + 2;                // input footprint rows
-constexpr int NV = 6;                     // 8-pixel packets per footprint row (34 pixels at any alignment)
-constexpr int LWP = NV * 8;               // pixels per LDS image row
 constexpr int kRow = 64;                  // bytes per LDS row (one pixel or one output channel, 32 channels)
-constexpr int kInBytes = LH * LWP * kRow; // 30720
 constexpr int kWBytes = 9 * BM * kRow;    // 36864
-constexpr int ROW_STEPS = LH / 2;         // a lane covers every second footprint row: 5 packets of 2 channels
+
+// Input footprint of a tile for convolution stride STEP (1 or 2) and its staging plan.
+template <int STEP> struct Geo {
+    static constexpr int LH = (TH - 1) * STEP + 3;                 // footprint rows: 10 / 17
+    static constexpr int LW = (TW - 1) * STEP + 3;                 // footprint columns: 34 / 65
+    static constexpr int NV = (LW + 7 + 7) / 8;                    // 8-pixel packets per row at any alignment: 6 / 9
+    static constexpr int LWP = NV * 8;                             // pixels per LDS image row
+    static constexpr int kInBytes = LH * LWP * kRow;               // 30720 / 78336
+    static constexpr int ITEMS = LH * NV;                          // (row, packet) items per channel pair
+    static constexpr int STEPS = (ITEMS + 15) / 16;                // items per lane: 4 / 10
+    static constexpr int BLOCKS_PER_CU = (kInBytes + kWBytes) * 2 <= 160 * 1024 ? 2 : 1;
+};
 
 template <class T> struct Mma16;
 template <> struct Mma16<__hip_bfloat16> {
@@ -65,11 +72,13 @@ template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) 
            ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
 }
 
-template <class T>
-__global__ void __launch_bounds__(kThreads, 2) conv3x3_kernel(Conv3x3Args g) {
+template <class T, int STEP>
+__global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_kernel(Conv3x3Args g) {
+    using G = Geo<STEP>;
+    constexpr int NV = G::NV, LWP = G::LWP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_in = smem;
-    unsigned char* s_w = smem + kInBytes;
+    unsigned char* s_w = smem + G::kInBytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
@@ -85,25 +94,26 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_kernel(Conv3x3Args g) {
     const T* __restrict__ x = (const T*)g.x + (unsigned)(n * g.ci * plane);   // fewer than 2^31 elements per tensor
     const T* __restrict__ w = (const T*)g.w;
 
-    // ---- input fetch: lane = (channel pair cg, packet v, row parity); 5 row steps ---------------------
-    const int cg = tid & 15, fv = (tid >> 4) & 7, fpar = tid >> 7;
-    const int px0 = b0 + g.px_shift + fv * 8;                       // first pixel column of this lane's packets
-    const bool col_ok = fv < NV && px0 >= 0 && px0 < g.wid;
-    const int iy_first = a0 + g.dy0 + fpar;
-    uint4 va[ROW_STEPS], vb[ROW_STEPS], vw[9];
+    // ---- input fetch: lane = (channel pair cg = tid & 15, item slot tid >> 4); item = (footprint row, packet) ------
+    const int cg = tid & 15, slot0 = tid >> 4;
+    const int px_first = b0 * STEP + g.px_shift;                    // first pixel column of the staged packets
+    const int iy_first = a0 * STEP + g.dy0;
+    uint4 va[G::STEPS], vb[G::STEPS], vw[9];
     float s0 = 1.f, s1 = 1.f;
 
     auto fetch = [&](int c0) {
         const int c = c0 + 2 * cg;
-        const bool c_ok = col_ok && c < g.ci, two = c + 1 < g.ci;
-        const T* src0 = x + (unsigned)(c * plane + px0);
+        const bool c_ok = c < g.ci, two = c + 1 < g.ci;
+        const T* src0 = x + (unsigned)(c * plane);
 #pragma unroll
-        for (int q = 0; q < ROW_STEPS; q++) {
-            const int iy = iy_first + 2 * q;
+        for (int q = 0; q < G::STEPS; q++) {
+            const int item = slot0 + 16 * q;
+            const int ry = item / NV, v = item - ry * NV;
+            const int iy = iy_first + ry, px0 = px_first + v * 8;
             va[q] = make_uint4(0, 0, 0, 0);
             vb[q] = make_uint4(0, 0, 0, 0);
-            if (c_ok && iy >= 0 && iy < g.h) {
-                const T* src = src0 + iy * g.wid;
+            if (c_ok && item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
+                const T* src = src0 + iy * g.wid + px0;
                 va[q] = *reinterpret_cast<const uint4*>(src);
                 if (two) vb[q] = *reinterpret_cast<const uint4*>(src + plane);
             }
@@ -123,20 +133,20 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_kernel(Conv3x3Args g) {
     };
 
     auto commit = [&]() {
-        if (fv < NV) {
 #pragma unroll
-            for (int q = 0; q < ROW_STEPS; q++) {
-                const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
-                const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
-                const int r0 = ((fpar + 2 * q) * NV + fv) * 8;   // a multiple of 8: the swizzle of row r0 + j is that of j
+        for (int q = 0; q < G::STEPS; q++) {
+            const int item = slot0 + 16 * q;
+            if (item >= G::ITEMS) continue;
+            const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
+            const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
+            const int r0 = item * 8;   // image row (ry * NV + v) * 8 + j: a multiple of 8, the swizzle of r0 + j is that of j
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
-                    unsigned out;
-                    if (g.in_scale) out = pack16<T>(lo16<T>(ea) * s0, lo16<T>(eb) * s1);
-                    else out = (ea & 0xffffu) | (eb << 16);
-                    *reinterpret_cast<unsigned*>(s_in + swz(r0 + j, cg * 4)) = out;
-                }
+            for (int j = 0; j < 8; j++) {
+                const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
+                unsigned out;
+                if (g.in_scale) out = pack16<T>(lo16<T>(ea) * s0, lo16<T>(eb) * s1);
+                else out = (ea & 0xffffu) | (eb << 16);
+                *reinterpret_cast<unsigned*>(s_in + swz(r0 + j, cg * 4)) = out;
             }
         }
 #pragma unroll
@@ -147,7 +157,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_kernel(Conv3x3Args g) {
     // n-tile j of wave w: output row 2w + (j >> 1), columns 16 (j & 1) .. +15; lane l addresses pixel column l & 15
     int brow[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * LWP + (j & 1) * 16 + lrow + g.px_col;
+    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * STEP * LWP + ((j & 1) * 16 + lrow) * STEP + g.px_col;
     const int a_lane = lrow * kRow + (((lgrp ^ (lrow >> 1)) & 3) << 4);
 
     f32x4_t acc[4][4];   // [channel tile m][pixel tile j]: rows = pixels 4 lgrp + r, column = channel lrow
@@ -278,18 +288,34 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_kernel(Conv3x3Args g) {
 
 bool conv3x3_eligible(const sg_conv2d_params& p) {
     if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
-    if (p.num_phases != 1 || p.in_step != 1 || p.out_step != 1) return false;
+    if (p.num_phases != 1 || p.in_step < 1 || p.in_step > 2 || p.out_step != 1) return false;
     const sg_conv2d_phase& ph = p.phase[0];
     if (ph.nky != 3 || ph.nkx != 3 || ph.oy0 != 0 || ph.ox0 != 0 || ph.w_offset != 0) return false;
-    if (p.ow < TW || p.oh < 5) return false;                      // the general kernel would pick the same 8 x 32 tile
+    if (p.ow < TW || p.oh < 5) return false;                      // smaller outputs would leave most of the 8 x 32 tile empty
     if (p.w_in % 8 != 0 || p.ow % 4 != 0 || p.ci % 8 != 0) return false;
-    if (p.ci <= 2 * KCH) return false;   // one or two chunks: nothing to overlap the loads with; the general kernel's finer
-                                         // scheduling (more independent workgroup phases) is faster there (measured)
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
     const auto aligned8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
     if (!aligned8(p.y) || (p.reduce_out && !aligned8(p.reduce_x))) return false;
     if (p.noise && (!aligned16(p.noise) || p.noise_stride_n % 4 != 0)) return false;
+    // Unit stride with one or two chunks: nothing to overlap the loads with; the general kernel's finer scheduling
+    // (more independent workgroup phases per CU) is faster there (measured).  The strided form wins from 32 channels.
+    if (p.in_step == 1 && p.ci <= 2 * KCH) return false;
+    if (p.in_step == 2 && p.ci < KCH) return false;
     return true;
+}
+
+int conv3x3_reduce_rows(const sg_conv2d_params& p) {
+    return ((p.oh + TH - 1) / TH) * ((p.ow + TW - 1) / TW);
+}
+
+template <class T, int STEP>
+static int launch_step(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
+    constexpr size_t lds = Geo<STEP>::kInBytes + kWBytes;
+    auto kernel = conv3x3_kernel<T, STEP>;
+    hipError_t e = allow_large_lds((const void*)kernel);
+    if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kThreads), lds, stream, g);
+    return check_launch("sg_conv2d");
 }
 
 int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
@@ -299,10 +325,11 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     g.noise = p.noise; g.noise_gain = p.noise_gain; g.reduce_x = p.reduce_x; g.reduce_out = p.reduce_out;
     g.n = p.n; g.ci = p.ci; g.co = p.co; g.h = p.h; g.wid = p.w_in; g.oh = p.oh; g.ow = p.ow;
     g.dy0 = p.phase[0].dy0;
-    // input column of output column b, tap kx: b + dx0 + kx.  Packets start at the multiple of 8 at or below b0 + dx0.
+    // input column of output column b, tap kx: b * step + dx0 + kx.  A tile's first output column is a multiple of 32,
+    // so its packets start at the multiple of 8 at or below dx0, relative to b0 * step.
     const int dx0 = p.phase[0].dx0;
     const int fl = (dx0 >= 0) ? dx0 / 8 : -((-dx0 + 7) / 8);
-    g.px_shift = fl * 8;            // first packet's pixel column relative to b0
+    g.px_shift = fl * 8;
     g.px_col = dx0 - g.px_shift;    // column of the footprint's first pixel inside the LDS image, 0..7
     g.tiles_a = (p.oh + TH - 1) / TH;
     g.tiles_b = (p.ow + TW - 1) / TW;
@@ -312,12 +339,9 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     g.hi = (p.clamp >= 0.f) ? p.clamp : __builtin_inff();
     const int64_t units = (int64_t)g.tiles_a * g.tiles_b * p.n * ((p.co + BM - 1) / BM);
     SG_REQUIRE(units <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
-    constexpr size_t lds = kInBytes + kWBytes;
-    auto kernel = (p.dtype == SG_BF16) ? conv3x3_kernel<__hip_bfloat16> : conv3x3_kernel<__half>;
-    hipError_t e = allow_large_lds((const void*)kernel);
-    if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kThreads), lds, stream, g);
-    return check_launch("sg_conv2d");
+    if (p.dtype == SG_BF16)
+        return (p.in_step == 1) ? launch_step<__hip_bfloat16, 1>(g, units, stream) : launch_step<__hip_bfloat16, 2>(g, units, stream);
+    return (p.in_step == 1) ? launch_step<__half, 1>(g, units, stream) : launch_step<__half, 2>(g, units, stream);
 }
 
 }  // namespace sg

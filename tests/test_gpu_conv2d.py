@@ -35,6 +35,11 @@ CASES = [  # name, n, ci, co, h, w, k, kind, stride, padding
     ('1x1_skip', 2, 64, 128, 16, 16, 1, 'conv', 1, 0),
     ('3x3_stride2', 2, 32, 64, 33, 33, 3, 'conv', 2, 0),
     ('3x3_stride2_ragged', 2, 24, 48, 21, 27, 3, 'conv', 2, 0),
+    ('3x3_stride2_wide', 2, 40, 72, 73, 80, 3, 'conv', 2, 0),      # the strided form of the 3x3 kernel: 36 x 39 -> not eligible (ow % 4)
+    ('3x3_stride2_wide2', 2, 40, 72, 75, 88, 3, 'conv', 2, 0),     # 37 x 43 ... see below for the eligible widths
+    ('3x3_stride2_fast', 3, 64, 136, 41, 72, 3, 'conv', 2, 1),     # 21 x 36 outputs, rows of whole packets: eligible
+    ('3x3_stride2_fast2', 2, 96, 64, 130, 136, 3, 'conv', 2, 0),   # 64 x 67 -> not eligible; 
+    ('3x3_stride2_fast3', 2, 96, 64, 67, 136, 3, 'conv', 2, 1),    # 34 x 68 outputs: eligible, ragged tiles
     ('3x3_nopad', 2, 32, 32, 18, 18, 3, 'conv', 1, 0),
     ('t3x3_up2', 2, 64, 32, 16, 16, 3, 'conv_transpose', 2, 0),
     ('t3x3_up2_pad1', 2, 32, 32, 9, 13, 3, 'conv_transpose', 2, 1),

@@ -14,6 +14,7 @@ LAYERS = [  # ci, co, h, dtype, kind
     (128, 64, 128, torch.bfloat16, 'up'), (256, 128, 64, torch.bfloat16, 'up'),
     (64, 3, 256, torch.bfloat16, '1x1'), (3, 64, 256, torch.bfloat16, '1x1'),
     (64, 128, 257, torch.bfloat16, 'down'),
+    (64, 128, 264, torch.bfloat16, 'down_t'), (128, 256, 136, torch.bfloat16, 'down_t'), (256, 512, 72, torch.bfloat16, 'down_t'),
 ]
 if os.environ.get('ONLY'):
     LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
@@ -35,7 +36,12 @@ def timeit(fn, iters=10):
 
 
 for ci, co, h, dtype, kind in LAYERS:
-    x = torch.randn([N, ci, h, h], device=DEV).to(dtype)
+    out_hw = None
+    if kind == 'down_t':   # as in training: blurred plane of (h - 7) rows, h columns (rows padded to whole packets)
+        kind, out_hw = 'down', ((h - 8) // 2, (h - 8) // 2)
+        x = torch.randn([N, ci, h - 7, h], device=DEV).to(dtype)
+    else:
+        x = torch.randn([N, ci, h, h], device=DEV).to(dtype)
     if kind == 'conv':
         w = torch.randn([co, ci, 3, 3], device=DEV).to(dtype) / 50
         plan = cp.plan_conv(3, 3, padding=1); packed = plan.pack(w)
@@ -56,7 +62,7 @@ for ci, co, h, dtype, kind in LAYERS:
         plan = cp.plan_conv_transpose(3, 3, stride=2); packed = plan.pack(w, transposed_layout=True)
         lib = lambda: F.conv_transpose2d(x, w, stride=2)
         taps = 9 / 4
-    ours = lambda: cp.conv2d(x, packed, plan, co)
+    ours = lambda: cp.conv2d(x, packed, plan, co, out_hw=out_hw)
     y = ours()
     if os.environ.get('NOLIB'):
         lib = ours
