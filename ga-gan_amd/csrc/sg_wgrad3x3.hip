@@ -24,17 +24,21 @@ typedef short v4i16_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
 
 constexpr int kThreads = 256;
-constexpr int TW = 32, TH = 8;
-constexpr int LH = TH + 2, LW = TW + 2;         // input footprint (pixels)
-constexpr int NV = 6;                            // 8-pixel packets covering a footprint row at any alignment
+constexpr int TW = 32;
 constexpr int BC = 64;                           // channels of either operand per workgroup
 constexpr int kPitch = 160;                      // bytes per LDS pixel row
-constexpr int kXBytes = LH * LW * kPitch;        // 54400
-constexpr int kGBytes = TH * TW * kPitch;        // 40960
-constexpr int X_ITEMS = LH * NV * (BC / 2);      // (row, packet, channel pair) items of the x footprint: 1920
-constexpr int G_ITEMS = TH * (TW / 8) * (BC / 2);   // 1024
-constexpr int X_STEPS = (X_ITEMS + kThreads - 1) / kThreads;   // 8
-constexpr int G_STEPS = G_ITEMS / kThreads;                    // 4
+
+// Tile of gradient pixels and the input footprint it needs, for convolution stride STEP (1 or 2).
+template <int STEP> struct WGeo {
+    static constexpr int TH = (STEP == 1) ? 8 : 4;             // gradient tile rows (x TW columns)
+    static constexpr int LH = (TH - 1) * STEP + 3;             // input footprint: 10 x 34 / 9 x 65 pixels
+    static constexpr int LW = (TW - 1) * STEP + 3;
+    static constexpr int NV = (LW + 7 + 7) / 8;                // 8-pixel packets covering a footprint row at any alignment
+    static constexpr int kXBytes = LH * LW * kPitch;           // 54400 / 93600
+    static constexpr int kGBytes = TH * TW * kPitch;           // 40960 / 20480
+    static constexpr int X_STEPS = (LH * NV + 7) / 8;          // (row, packet) items per lane: 8 / 11
+    static constexpr int G_STEPS = TH * (TW / 8) / 8;          // 4 / 2
+};
 
 template <class T> struct Mma16;
 template <> struct Mma16<__hip_bfloat16> {
@@ -72,11 +76,13 @@ struct Wgrad3x3Args {
     int tiles_a, tiles_b, tiles_total;
 };
 
-template <class T>
+template <class T, int STEP>
 __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
+    using G = WGeo<STEP>;
+    constexpr int TH = G::TH, LH = G::LH, LW = G::LW, NV = G::NV, X_STEPS = G::X_STEPS, G_STEPS = G::G_STEPS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_x = smem;
-    unsigned char* s_g = smem + kXBytes;
+    unsigned char* s_g = smem + G::kXBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int cg0 = blockIdx.y * BC, cx0 = blockIdx.z * BC;
@@ -102,7 +108,7 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
             for (int s = 0; s < X_STEPS; s++) {
                 const int r = (tid >> 5) + 8 * s;          // item row index = ry * NV + v
                 const int v = r % NV, ry = r / NV;
-                const int iy = a0 + p.dy0 + ry, px0 = b0 + p.px_shift + v * 8;
+                const int iy = a0 * STEP + p.dy0 + ry, px0 = b0 * STEP + p.px_shift + v * 8;
                 xa[s] = make_uint4(0, 0, 0, 0);
                 xb[s] = make_uint4(0, 0, 0, 0);
                 if (c_ok && ry < LH && iy >= 0 && iy < p.h && px0 >= 0 && px0 < p.wid) {
@@ -179,7 +185,7 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
     for (int hf = 0; hf < 2; hf++) {
         const int col = 4 * lgrp + 16 * hf + q;
         off_g[hf] = col * kPitch + pq * 8 + wm * 64;   // + m * 32 + ks * TW * kPitch
-        off_x[hf] = col * kPitch + pq * 8 + wn * 64;   // + n * 32 + ((ks + ky) * LW + kx) * kPitch
+        off_x[hf] = col * STEP * kPitch + pq * 8 + wn * 64;   // + n * 32 + ((ks * STEP + ky) * LW + kx) * kPitch
     }
 
     f32x4_t acc[9][2][2];
@@ -210,7 +216,7 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
                 const int ky = tp / 3, kx = tp % 3;
 #pragma unroll
                 for (int n = 0; n < 2; n++) {
-                    const unsigned char* base = s_x + ((ks + ky) * LW + kx) * kPitch + n * 32;
+                    const unsigned char* base = s_x + ((ks * STEP + ky) * LW + kx) * kPitch + n * 32;
                     const uint4 b = fetch_frag(base + off_x[0], base + off_x[1]);
 #pragma unroll
                     for (int m = 0; m < 2; m++) Mma16<T>::run(a[m], b, acc[tp][m][n]);
@@ -238,12 +244,33 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
 
 bool wgrad3x3_eligible(const sg_conv2d_wgrad_params& p) {
     if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
-    if (p.step != 1 || p.nky != 3 || p.nkx != 3) return false;
-    if (p.gw < TW || p.gh < TH) return false;
+    if (p.step < 1 || p.step > 2 || p.nky != 3 || p.nkx != 3) return false;
+    if (p.gw < TW || p.gh < (p.step == 1 ? 8 : 4)) return false;
     if (p.w_in % 8 != 0 || p.gw % 8 != 0) return false;
     if (!aligned16(p.x) || !aligned16(p.g)) return false;
     if (p.cx < 32 || p.cg < 32) return false;   // a 64 x 64 block would be mostly padding
     return true;
+}
+
+template <class T, int STEP>
+static int launch_wstep(Wgrad3x3Args& a, const sg_conv2d_wgrad_params& p, hipStream_t stream) {
+    using G = WGeo<STEP>;
+    a.tiles_a = (p.gh + G::TH - 1) / G::TH;
+    a.tiles_b = (p.gw + TW - 1) / TW;
+    const int64_t tiles = (int64_t)a.tiles_a * a.tiles_b * p.n;
+    SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: too many tiles");
+    a.tiles_total = (int)tiles;
+    const int blocks_g = (p.cg + BC - 1) / BC, blocks_x = (p.cx + BC - 1) / BC;
+    // one workgroup per CU: split the pixel tiles so that the (cg, cx) blocks times the split fill the chip
+    int64_t split = (256 + (int64_t)blocks_g * blocks_x - 1) / ((int64_t)blocks_g * blocks_x);
+    if (split > tiles) split = tiles;
+    if (split < 1) split = 1;
+    constexpr size_t lds = G::kXBytes + G::kGBytes;
+    auto kernel = wgrad3x3_kernel<T, STEP>;
+    hipError_t e = allow_large_lds((const void*)kernel);
+    if (e != hipSuccess) return fail((int)e, "conv2d_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)split, (unsigned)blocks_g, (unsigned)blocks_x), dim3(kThreads), lds, stream, a);
+    return check_launch("sg_conv2d_wgrad");
 }
 
 int wgrad3x3_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
@@ -254,22 +281,9 @@ int wgrad3x3_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
     const int fl = (p.dx0 >= 0) ? p.dx0 / 8 : -((-p.dx0 + 7) / 8);
     a.px_shift = fl * 8;
     a.px_col = p.dx0 - a.px_shift;
-    a.tiles_a = (p.gh + TH - 1) / TH;
-    a.tiles_b = (p.gw + TW - 1) / TW;
-    const int64_t tiles = (int64_t)a.tiles_a * a.tiles_b * p.n;
-    SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: too many tiles");
-    a.tiles_total = (int)tiles;
-    const int blocks_g = (p.cg + BC - 1) / BC, blocks_x = (p.cx + BC - 1) / BC;
-    // one workgroup per CU: split the pixel tiles so that the (cg, cx) blocks times the split fill the chip
-    int64_t split = (256 + (int64_t)blocks_g * blocks_x - 1) / ((int64_t)blocks_g * blocks_x);
-    if (split > tiles) split = tiles;
-    if (split < 1) split = 1;
-    constexpr size_t lds = kXBytes + kGBytes;
-    auto kernel = (p.dtype == SG_BF16) ? wgrad3x3_kernel<__hip_bfloat16> : wgrad3x3_kernel<__half>;
-    hipError_t e = allow_large_lds((const void*)kernel);
-    if (e != hipSuccess) return fail((int)e, "conv2d_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)split, (unsigned)blocks_g, (unsigned)blocks_x), dim3(kThreads), lds, stream, a);
-    return check_launch("sg_conv2d_wgrad");
+    if (p.dtype == SG_BF16)
+        return (p.step == 1) ? launch_wstep<__hip_bfloat16, 1>(a, p, stream) : launch_wstep<__hip_bfloat16, 2>(a, p, stream);
+    return (p.step == 1) ? launch_wstep<__half, 1>(a, p, stream) : launch_wstep<__half, 2>(a, p, stream);
 }
 
 }  // namespace sg

@@ -180,3 +180,31 @@ def test_conv2d_wgrad_transposed_roles():
     want, = torch.autograd.grad(y, wt, dy.double())
     dw = cp.conv2d_wgrad(dy.to(DEV), x.to(DEV), 3, 3, stride=2, padding=0)
     close(dw, want, 1e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 40, 72, 41, 72, 20, 32), (3, 64, 136, 23, 136, 11, 64), (2, 96, 64, 9, 80, 4, 40)],
+                         ids=['40to72', '64to136', '96to64'])
+def test_conv2d_wgrad_stride2_cropped(shape, dtype):
+    """Stride-2 weight gradient with a gradient plane narrower than the convolution's natural output (rows of
+    whole packets, as the down-sampling layers produce them): the 3x3 strided weight-gradient kernel."""
+    from ga_gan_amd import conv2d_plugin as cp
+    n, ci, co, h, w, gh, gw = shape
+    g = torch.Generator().manual_seed(ci + gw)
+    x = torch.randn([n, ci, h, w], generator=g).to(dtype)
+    wt = torch.zeros([co, ci, 3, 3], dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), wt, stride=2, padding=1)
+    assert y.shape[2] >= gh and y.shape[3] >= gw
+    dy = torch.randn([n, co, gh, gw], generator=g).to(dtype)
+    dy_full = torch.zeros(y.shape, dtype=torch.float64)
+    dy_full[:, :, :gh, :gw] = dy.double()
+    want, = torch.autograd.grad(y, wt, dy_full)
+    xs, gs = torch.rand([n, ci], generator=g) + 0.5, torch.rand([n, co], generator=g) + 0.5
+    dw = cp.conv2d_wgrad(x.to(DEV), dy.to(DEV), 3, 3, stride=2, padding=1)
+    close(dw, want, 1e-4, 'plain')
+    x2 = (x.float() * xs.reshape(n, ci, 1, 1)).to(dtype)
+    dy2 = torch.zeros(y.shape, dtype=torch.float64)
+    dy2[:, :, :gh, :gw] = (dy.float() * gs.reshape(n, co, 1, 1)).to(dtype).double()
+    want2, = torch.autograd.grad(F.conv2d(x2.double(), wt, stride=2, padding=1), wt, dy2)
+    dw2 = cp.conv2d_wgrad(x.to(DEV), dy.to(DEV), 3, 3, stride=2, padding=1, x_scale=xs.to(DEV), g_scale=gs.to(DEV))
+    close(dw2, want2, 1e-4, 'scaled')

@@ -7,8 +7,6 @@ from ga_gan_amd import conv2d_plugin as cp
 N = int(os.environ.get('N', 32))
 LAYERS = [(64, 64, 256, torch.bfloat16), (128, 128, 128, torch.bfloat16), (256, 256, 64, torch.bfloat16),
           (512, 512, 32, torch.bfloat16), (512, 512, 16, torch.float32), (512, 512, 8, torch.float32)]
-if os.environ.get('ONLY'):
-    LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
 
 
 def timeit(fn, iters=10):
@@ -24,10 +22,18 @@ def timeit(fn, iters=10):
     return s.elapsed_time(e) / iters
 
 
+LAYERS += [(64, 128, -264, torch.bfloat16), (128, 256, -136, torch.bfloat16), (256, 512, -72, torch.bfloat16)]   # h < 0: stride 2, input h x h
 for ci, co, h, dtype in LAYERS:
-    x = torch.randn([N, ci, h, h], device='cuda').to(dtype)
-    g = torch.randn([N, co, h, h], device='cuda').to(dtype)
-    fn = lambda: cp.conv2d_wgrad(x, g, 3, 3, stride=1, padding=1)
+    stride = 1
+    if h < 0:
+        stride, h = 2, -h
+        x = torch.randn([N, ci, h - 7, h], device='cuda').to(dtype)
+        h = (h - 8) // 2
+        g = torch.randn([N, co, h, h], device='cuda').to(dtype)
+    else:
+        x = torch.randn([N, ci, h, h], device='cuda').to(dtype)
+        g = torch.randn([N, co, h, h], device='cuda').to(dtype)
+    fn = lambda: cp.conv2d_wgrad(x, g, 3, 3, stride=stride, padding=1 if stride == 1 else 0)
     t = timeit(fn)
     flops = 2.0 * N * co * ci * 9 * h * h
     nbytes = (x.numel() + g.numel()) * x.element_size()
