@@ -97,7 +97,7 @@ def kernel_roofline(trainer, real, real_c, steps):
     summary = {n: dict(launches_per_step=v['launches'] // steps, ms_per_step=round(v['ms'] / steps, 3),
                        gbps=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1),
                        tflops=round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 2))
-               for n, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]['ms'])}
+               for n, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]['ms'])[:8]}   # the eight heaviest symbols
     return roofline, summary
 
 
@@ -212,7 +212,7 @@ def main():
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
                    config=dict(workload=desc, resolution=res, global_batch=global_batch, per_gpu_batch=batch_gpu,
                                parallelism=f'dp{world}', hip_graphs=bool(trainer.use_graphs), iteration='Gmain+Dmain every step, Greg every 4th, Dreg every 16th',
-                               kernels='conv2d / conv2d_wgrad (MFMA), upfirdn2d, bias_act, minibatch-std: hand-written HIP; small GEMMs: torch'),
+                               kernels='conv2d / conv3x3 / wgrad (MFMA), upfirdn2d, layer epilogues, bias_act, minibatch-std: hand-written HIP; small GEMMs: torch'),
                    roofline=roofline, cpu_baseline=baseline, kernels=kernels,
                    grad_exchange_bytes_per_step=int(trainer.exchanged_bytes / max(trainer.batch_idx, 1)))
         print(json.dumps(out), flush=True)
