@@ -58,6 +58,23 @@ def make_trainer(args, rank, world):
     return training_loop.Trainer(rank=rank, random_seed=0, use_graphs=bool(getattr(args, 'graphs', False)), **opts), desc, res, batch_gpu
 
 
+def measured_traffic(label):
+    """HBM-side bytes per launch of the kernel `label` (symbol<dtype>) from the committed counter runs of this same
+    command (profiles/r1_traffic.json, written by tools/summarize_traffic.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
+    passes); None when the file has no entry.  All template instances of the symbol and dtype are pooled."""
+    path = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+    if not os.path.isfile(path):
+        return None
+    symbol, _, dtype = label.partition('<')
+    dtype = dtype.rstrip('>').split(',')[0]
+    total, launches = 0.0, 0
+    for name, v in json.load(open(path))['kernels'].items():
+        if name.startswith(symbol + '<') and name[len(symbol) + 1:].startswith(dtype):
+            total += v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch'])
+            launches += v['launches']
+    return int(total / launches) if launches else None
+
+
 def kernel_roofline(trainer, real, real_c, steps):
     """Instrumented pass: HIP events around every launch of the hand-written kernels (recorded on the
     stream they are launched on), grouped by kernel symbol.  The kernel with the largest total time is the
@@ -86,13 +103,13 @@ def kernel_roofline(trainer, real, real_c, steps):
         peak = MFMA_PEAK_TFLOPS['float' if '<float' in name else 'bf16']
         achieved = (k['flops'] / k['launches']) / (avg_ms * 1e-3) / 1e12
         roofline = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 4), traffic=None, launches=k['launches'],
+                        frac=round(achieved / peak, 4), traffic=measured_traffic(name), launches=k['launches'],
                         avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_flops_per_launch=int(k['flops'] / k['launches']),
                         algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
     else:
         achieved = (k['bytes'] / k['launches']) / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None, launches=k['launches'],
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(name), launches=k['launches'],
                         avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
     summary = {n: dict(launches_per_step=v['launches'] // steps, ms_per_step=round(v['ms'] / steps, 3),
                        gbps=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1),

@@ -804,7 +804,8 @@ extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
 
 extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
     if (p == nullptr) return "";
-    return sg::conv3x3_eligible(*p) ? "conv3x3_kernel" : "conv2d_mfma_kernel";
+    if (!sg::conv3x3_eligible(*p)) return "conv2d_mfma_kernel";
+    return sg::conv3x3_resident(*p) ? "conv3x3_resident_kernel" : "conv3x3_kernel";
 }
 
 extern "C" const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p) {

@@ -16,12 +16,14 @@ struct Conv3x3Args {
     int px_shift;        // pixel column (relative to the tile's first input column b0 * step) where the staged packets start
     int px_col;          // column of the footprint's first pixel inside the staged image, 0..7
     int tiles_a, tiles_b;
+    int units;           // tiles x output-channel blocks
     int noise_stride;
     float slope, gain, hi;   // leaky-ReLU slope (1: linear), output gain, clamp bound (+inf: none)
 };
 
 bool conv3x3_eligible(const sg_conv2d_params& p);
 int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
+bool conv3x3_resident(const sg_conv2d_params& p);       // eligible and narrow (<= 64 channels both sides): weights stay in LDS
 int conv3x3_reduce_rows(const sg_conv2d_params& p);   // partial rows per sample of the reduction, for eligible geometries
 
 // Weight gradient of the same geometry (sg_wgrad3x3.hip); sg_conv2d_wgrad dispatches.

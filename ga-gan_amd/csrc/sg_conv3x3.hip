@@ -21,6 +21,9 @@
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
+#include <algorithm>
+#include <atomic>
+
 namespace sg {
 namespace {
 
@@ -83,8 +86,11 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
 
-    // ---- which tile ---------------------------------------------------------------------------------
-    int unit = blockIdx.x;
+    // ---- which tile: workgroups are dealt to the 8 XCDs round-robin; XCD k takes the k-th contiguous eighth of the
+    // tiles, so that neighbouring tiles (shared halo rows and packets) meet in one L2 --------------------------------
+    const int per_xcd = (g.units + 7) >> 3;
+    int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= g.units) return;
     const int tb = unit % g.tiles_b; unit /= g.tiles_b;
     const int ta = unit % g.tiles_a; unit /= g.tiles_a;
     const int n = unit % g.n;
@@ -284,6 +290,217 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Narrow layers (at most 64 input and 64 output channels: the 256^2 ... 1024^2 layers, whose arithmetic
+// intensity puts them at or near the HBM roofline): the whole weight tensor (<= 72 KB) stays in LDS for the
+// lifetime of a persistent workgroup, which then only streams pixel tiles: all input channels of the next tile
+// are loaded into registers while the current tile is multiplied, and the epilogue's operands are loaded ahead of
+// the multiply phase.  CHUNKS = ceil(ci / 32), M_TILES = ceil(co / 16).  Unit stride only.
+template <class T, int CHUNKS, int M_TILES>
+__global__ void __launch_bounds__(kThreads, (CHUNKS == 1) ? 2 : 1) conv3x3_resident_kernel(Conv3x3Args g, int units) {
+    using G = Geo<1>;
+    constexpr int NV = G::NV, LWP = G::LWP, BMW = 16 * M_TILES;
+    constexpr int kWChunk = 9 * BMW * kRow;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_w = smem;                             // [chunk][tap][BMW][32 channels]
+    unsigned char* s_in = smem + CHUNKS * kWChunk;         // [chunk][footprint pixel][32 channels]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int plane = g.h * g.wid;
+    const T* __restrict__ w = (const T*)g.w;
+
+    // ---- weights: once per workgroup ------------------------------------------------------------------------
+    for (int e = tid; e < CHUNKS * 9 * BMW * 4; e += kThreads) {
+        const int slot = e & 3, row = (e >> 2) % (9 * BMW), ch = (e >> 2) / (9 * BMW);   // row = tap * BMW + o
+        const int o = row % BMW, tap = row / BMW, c = ch * KCH + slot * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (o < g.co && c < g.ci) v = *reinterpret_cast<const uint4*>(w + (unsigned)((tap * g.co + o) * g.ci + c));
+        *reinterpret_cast<uint4*>(s_w + ch * kWChunk + swz(row, slot * 16)) = v;
+    }
+
+    // ---- input fetch / commit: as conv3x3_kernel, all chunks of a tile at once ---------------------------------
+    const int cg = tid & 15, slot0 = tid >> 4;
+    uint4 va[CHUNKS][G::STEPS], vb[CHUNKS][G::STEPS];
+    float s0[CHUNKS], s1[CHUNKS];
+    auto decode = [&](int unit, int& n, int& a0, int& b0) {
+        const int tb = unit % g.tiles_b; unit /= g.tiles_b;
+        const int ta = unit % g.tiles_a;
+        n = unit / g.tiles_a;
+        a0 = ta * TH; b0 = tb * TW;
+    };
+    auto fetch = [&](int unit) {
+        int n, a0, b0;
+        decode(unit, n, a0, b0);
+        const T* x = (const T*)g.x + (unsigned)(n * g.ci * plane);
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ch++) {
+            const int c = ch * KCH + 2 * cg;
+            const bool c_ok = c < g.ci, two = c + 1 < g.ci;
+            const T* src0 = x + (unsigned)(c * plane);
+#pragma unroll
+            for (int q = 0; q < G::STEPS; q++) {
+                const int item = slot0 + 16 * q;
+                const int ry = item / NV, v = item - ry * NV;
+                const int iy = a0 + g.dy0 + ry, px0 = b0 + g.px_shift + v * 8;
+                va[ch][q] = make_uint4(0, 0, 0, 0);
+                vb[ch][q] = make_uint4(0, 0, 0, 0);
+                if (c_ok && item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
+                    const T* src = src0 + iy * g.wid + px0;
+                    va[ch][q] = *reinterpret_cast<const uint4*>(src);
+                    if (two) vb[ch][q] = *reinterpret_cast<const uint4*>(src + plane);
+                }
+            }
+            s0[ch] = 1.f; s1[ch] = 1.f;
+            if (g.in_scale) {
+                s0[ch] = c_ok ? g.in_scale[n * g.ci + c] : 0.f;
+                s1[ch] = two ? g.in_scale[n * g.ci + c + 1] : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ch++)
+#pragma unroll
+            for (int q = 0; q < G::STEPS; q++) {
+                const int item = slot0 + 16 * q;
+                if (item >= G::ITEMS) continue;
+                const unsigned wa[4] = {va[ch][q].x, va[ch][q].y, va[ch][q].z, va[ch][q].w};
+                const unsigned wb[4] = {vb[ch][q].x, vb[ch][q].y, vb[ch][q].z, vb[ch][q].w};
+                const int r0 = item * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
+                    unsigned out;
+                    if (g.in_scale) out = pack16<T>(lo16<T>(ea) * s0[ch], lo16<T>(eb) * s1[ch]);
+                    else out = (ea & 0xffffu) | (eb << 16);
+                    *reinterpret_cast<unsigned*>(s_in + ch * G::kInBytes + swz(r0 + j, cg * 4)) = out;
+                }
+            }
+    };
+
+    int brow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * LWP + (j & 1) * 16 + lrow + g.px_col;
+    const int a_lane = lrow * kRow + (((lgrp ^ (lrow >> 1)) & 3) << 4);
+    const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
+    const int ch0 = lrow;
+    const int ch_stride = 16 * g.oh * g.ow;
+    T* __restrict__ y = (T*)g.y;
+
+    // Workgroups are dealt to the 8 XCDs round-robin; each XCD (own L2) takes a contiguous range of the tiles and its
+    // workgroups walk it together in raster order, so that the halo rows and the packets shared by neighbouring tiles
+    // are found in that L2 instead of being fetched once per XCD.
+    const int xcd = blockIdx.x & 7, per_xcd = (units + 7) >> 3, stride = gridDim.x >> 3;
+    const int unit_end = min(units, (xcd + 1) * per_xcd);
+    int unit = xcd * per_xcd + (blockIdx.x >> 3);
+    if (unit < unit_end) fetch(unit);
+    for (; unit < unit_end; unit += stride) {
+        int n, a0, b0;
+        decode(unit, n, a0, b0);
+        __syncthreads();   // everyone is done reading the previous tile (and, the first time, the weights are in place)
+        commit();
+        __syncthreads();
+        if (unit + stride < unit_end) fetch(unit + stride);   // next tile: in flight during this tile's multiply phase
+
+        // ---- epilogue operands of this tile, loaded ahead of the multiply phase ------------------------------------
+        float sc[M_TILES], bs[M_TILES];
+        float4 nz[4];
+        uint2 rx[4][M_TILES];
+        unsigned off0[4];
+        bool inside[4];
+#pragma unroll
+        for (int m = 0; m < M_TILES; m++) {
+            const int ch = min(ch0 + 16 * m, g.co - 1);
+            sc[m] = g.out_scale ? g.out_scale[n * g.co + ch] : 1.f;
+            bs[m] = g.bias ? Elem<T>::load(((const T*)g.bias)[ch]) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int a = a0 + 2 * wave + (j >> 1), b = b0 + (j & 1) * 16 + 4 * lgrp;
+            inside[j] = a < g.oh && b < g.ow;
+            off0[j] = (unsigned)(((n * g.co + ch0) * g.oh + a) * g.ow + b);
+            nz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.noise && inside[j]) nz[j] = *reinterpret_cast<const float4*>(g.noise + n * g.noise_stride + a * g.ow + b);
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++) {
+                rx[j][m] = make_uint2(0, 0);
+                if (g.reduce_out && inside[j] && ch0 + 16 * m < g.co)
+                    rx[j][m] = *reinterpret_cast<const uint2*>((const T*)g.reduce_x + off0[j] + m * ch_stride);
+            }
+        }
+
+        // ---- multiply: chunks x 9 taps, fragments of the next tap read while this one multiplies -------------------
+        f32x4_t acc[M_TILES][4];
+#pragma unroll
+        for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint4 fa[2][M_TILES], fb[2][4];
+        auto read_tap = [&](int t, uint4 (&a)[M_TILES], uint4 (&b)[4]) {   // t = chunk * 9 + tap
+            const int ch = t / 9, tap = t % 9, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++)
+                a[m] = *reinterpret_cast<const uint4*>(s_w + ch * kWChunk + (tap * BMW + m * 16) * kRow + a_lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = brow[j] + ky * LWP + kx;
+                b[j] = *reinterpret_cast<const uint4*>(s_in + ch * G::kInBytes + row * kRow + (((lgrp ^ (row >> 1)) & 3) << 4));
+            }
+        };
+        read_tap(0, fa[0], fb[0]);
+#pragma unroll
+        for (int t = 0; t < CHUNKS * 9; t++) {
+            if (t + 1 < CHUNKS * 9) read_tap(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int m = 0; m < M_TILES; m++) Mma16<T>::run(fb[t & 1][j], fa[t & 1][m], acc[m][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue -------------------------------------------------------------------------------------------
+        float red[M_TILES];
+#pragma unroll
+        for (int m = 0; m < M_TILES; m++) red[m] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float nzj[4] = {nz[j].x * noise_gain, nz[j].y * noise_gain, nz[j].z * noise_gain, nz[j].w * noise_gain};
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++) {
+                if (!inside[j] || ch0 + 16 * m >= g.co) continue;
+                float v[4] = {acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
+                red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float e = v[r] * sc[m] + nzj[r] + bs[m];
+                    e = (e > 0.f) ? e : e * g.slope;
+                    v[r] = fminf(fmaxf(e * g.gain, -g.hi), g.hi);
+                }
+                *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = make_uint2(pack16<T>(v[0], v[1]), pack16<T>(v[2], v[3]));
+            }
+        }
+        if (g.reduce_out) {
+            // lanes l, l+16, l+32, l+48 share their channels; then the four waves through the input image's LDS
+            __syncthreads();   // every wave has left the multiply loop
+            float* s_red = reinterpret_cast<float*>(s_in);
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++) {
+                float r = red[m];
+                r += __shfl_xor(r, 16, 64);
+                r += __shfl_xor(r, 32, 64);
+                if (lgrp == 0) s_red[wave * BMW + m * 16 + lrow] = r;
+            }
+            __syncthreads();
+            if (tid < BMW && tid < g.co) {
+                const float r = s_red[tid] + s_red[BMW + tid] + s_red[2 * BMW + tid] + s_red[3 * BMW + tid];
+                g.reduce_out[(unsigned)(unit * g.co + tid)] = r;   // unit = (n * tiles_a + ta) * tiles_b + tb
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool conv3x3_eligible(const sg_conv2d_params& p) {
@@ -297,15 +514,50 @@ bool conv3x3_eligible(const sg_conv2d_params& p) {
     const auto aligned8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
     if (!aligned8(p.y) || (p.reduce_out && !aligned8(p.reduce_x))) return false;
     if (p.noise && (!aligned16(p.noise) || p.noise_stride_n % 4 != 0)) return false;
-    // Unit stride with one or two chunks: nothing to overlap the loads with; the general kernel's finer scheduling
-    // (more independent workgroup phases per CU) is faster there (measured).  The strided form wins from 32 channels.
-    if (p.in_step == 1 && p.ci <= 2 * KCH) return false;
+    // Unit stride with one or two chunks goes to the weights-resident kernel when the output is narrow too; a wide
+    // output with a narrow input stays on the general kernel.  The strided form wins from 32 channels.
+    if (p.in_step == 1 && p.ci <= 2 * KCH && p.co > BM) return false;
     if (p.in_step == 2 && p.ci < KCH) return false;
     return true;
 }
 
+bool conv3x3_resident(const sg_conv2d_params& p) {   // among the eligible geometries: the weights-resident kernel
+    return p.in_step == 1 && p.ci <= 2 * KCH && p.co <= BM;
+}
+
 int conv3x3_reduce_rows(const sg_conv2d_params& p) {
     return ((p.oh + TH - 1) / TH) * ((p.ow + TW - 1) / TW);
+}
+
+int compute_units() {   // of the current device; asked once per process and device
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int cu = cached[dev].load(std::memory_order_relaxed);
+    if (cu == 0) {
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1) cu = 256;
+        cached[dev].store(cu, std::memory_order_relaxed);
+    }
+    return cu;
+}
+
+template <class T, int CHUNKS, int M_TILES>
+static int launch_resident(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
+    constexpr size_t lds = (size_t)CHUNKS * (9 * 16 * M_TILES * kRow + Geo<1>::kInBytes);
+    auto kernel = conv3x3_resident_kernel<T, CHUNKS, M_TILES>;
+    hipError_t e = allow_large_lds((const void*)kernel);
+    if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    const int per_cu = (CHUNKS == 1) ? std::min<int>(2, (int)((160 * 1024) / lds)) : 1;
+    const int64_t grid = std::max<int64_t>(8, std::min<int64_t>((units + 7) / 8 * 8, (int64_t)per_cu * compute_units()) / 8 * 8);   // a multiple of the 8 XCDs
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kThreads), lds, stream, g, (int)units);
+    return check_launch("sg_conv2d");
+}
+
+template <class T>
+static int launch_resident_for(const Conv3x3Args& g, int64_t units, int ci, int co, hipStream_t stream) {
+    const bool one = ci <= KCH, narrow = co <= 32;
+    if (one) return narrow ? launch_resident<T, 1, 2>(g, units, stream) : launch_resident<T, 1, 4>(g, units, stream);
+    return narrow ? launch_resident<T, 2, 2>(g, units, stream) : launch_resident<T, 2, 4>(g, units, stream);
 }
 
 template <class T, int STEP>
@@ -314,7 +566,7 @@ static int launch_step(const Conv3x3Args& g, int64_t units, hipStream_t stream) 
     auto kernel = conv3x3_kernel<T, STEP>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kThreads), lds, stream, g);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 7) / 8 * 8)), dim3(kThreads), lds, stream, g);
     return check_launch("sg_conv2d");
 }
 
@@ -338,7 +590,11 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     g.gain = p.gain;
     g.hi = (p.clamp >= 0.f) ? p.clamp : __builtin_inff();
     const int64_t units = (int64_t)g.tiles_a * g.tiles_b * p.n * ((p.co + BM - 1) / BM);
-    SG_REQUIRE(units <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
+    SG_REQUIRE(units <= INT32_MAX - 8, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
+    g.units = (int)units;
+    if (conv3x3_resident(p))
+        return (p.dtype == SG_BF16) ? launch_resident_for<__hip_bfloat16>(g, units, p.ci, p.co, stream)
+                                    : launch_resident_for<__half>(g, units, p.ci, p.co, stream);
     if (p.dtype == SG_BF16)
         return (p.in_step == 1) ? launch_step<__hip_bfloat16, 1>(g, units, stream) : launch_step<__hip_bfloat16, 2>(g, units, stream);
     return (p.in_step == 1) ? launch_step<__half, 1>(g, units, stream) : launch_step<__half, 2>(g, units, stream);

@@ -5,6 +5,8 @@ Tolerance: float32 kernels use exact-float32 MFMA (an fma chain) -> 2e-5 of the 
 magnitude; bf16 / fp16 kernels multiply 16-bit operands exactly, accumulate in float32 and round
 once on store -> one unit in the last place of the storage type (2^-8 / 2^-11), doubled when the
 scaled input is rounded to the storage type before the multiply (in_scale)."""
+import zlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -27,6 +29,9 @@ CASES = [  # name, n, ci, co, h, w, k, kind, stride, padding
     ('3x3_big', 2, 64, 64, 64, 64, 3, 'conv', 1, 1),
     ('3x3_ragged', 3, 40, 72, 19, 23, 3, 'conv', 1, 1),
     ('3x3_lowres', 5, 64, 128, 4, 4, 3, 'conv', 1, 1),
+    ('3x3_narrow', 3, 32, 32, 40, 72, 3, 'conv', 1, 1),        # the weights-resident kernel: one chunk, two channel tiles
+    ('3x3_narrow_ragged', 2, 24, 48, 36, 40, 3, 'conv', 1, 1),  # one chunk (partly filled), four channel tiles
+    ('3x3_narrow2', 5, 56, 24, 19, 64, 3, 'conv', 1, 1),       # two chunks, two channel tiles, more tiles than workgroups would need
     ('3x3_wide', 2, 96, 80, 40, 40, 3, 'conv', 1, 1),          # the 3x3 unit-stride kernel, ragged channels and tiles
     ('3x3_wide_rect', 3, 72, 136, 36, 64, 3, 'conv', 1, 1),
     ('3x3_8x8', 9, 32, 64, 8, 8, 3, 'conv', 1, 1),
@@ -52,7 +57,7 @@ CASES = [  # name, n, ci, co, h, w, k, kind, stride, padding
 def test_conv2d_plain(case, dtype):
     from ga_gan_amd import conv2d_plugin as cp
     name, n, ci, co, h, w, k, kind, stride, padding = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn([n, ci, h, w], generator=g).to(dtype)
     if kind == 'conv':
         wt = (torch.randn([co, ci, k, k], generator=g) / (ci * k * k) ** 0.5).to(dtype)
@@ -150,7 +155,7 @@ WGRAD_CASES = [  # name, n, ci, co, h, w, k, stride, padding
 def test_conv2d_wgrad(case, dtype):
     from ga_gan_amd import conv2d_plugin as cp
     name, n, ci, co, h, w, k, stride, padding = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn([n, ci, h, w], generator=g).to(dtype)
     wt = torch.zeros([co, ci, k, k], dtype=torch.float64, requires_grad=True)
     y = F.conv2d(x.double(), wt, stride=stride, padding=padding)
@@ -166,7 +171,8 @@ def test_conv2d_wgrad(case, dtype):
     dy2 = (dy.float() * gs.reshape(n, co, 1, 1)).to(dtype)
     want2, = torch.autograd.grad(F.conv2d(x2.double(), wt, stride=stride, padding=padding), wt, dy2.double())
     dw2 = cp.conv2d_wgrad(x.to(DEV), dy.to(DEV), k, k, stride=stride, padding=padding, x_scale=xs.to(DEV), g_scale=gs.to(DEV))
-    close(dw2, want2, 2e-5 if dtype == torch.float32 else 1e-4, name + ' scaled')
+    # (a scaled operand that lands on a rounding tie may round the other way on the device: one unit in its last place)
+    close(dw2, want2, 2e-5 if dtype == torch.float32 else 4e-4, name + ' scaled')
 
 
 def test_conv2d_wgrad_transposed_roles():
