@@ -765,6 +765,7 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->w && p->y, SG_ERR_NULL_POINTER, "conv2d: x, w and y must not be NULL");
     if (conv3x3_eligible(*p)) return conv3x3_launch(*p, (hipStream_t)stream);
+    if (conv_up2_eligible(*p)) return conv_up2_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
         case SG_F32: return launch<float>(*p, (hipStream_t)stream);
         case SG_F16: return launch<__half>(*p, (hipStream_t)stream);
@@ -804,6 +805,7 @@ extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
 
 extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
     if (p == nullptr) return "";
+    if (sg::conv_up2_eligible(*p)) return "conv_up2_kernel";
     if (!sg::conv3x3_eligible(*p)) return "conv2d_mfma_kernel";
     return sg::conv3x3_resident(*p) ? "conv3x3_resident_kernel" : "conv3x3_kernel";
 }

@@ -26,6 +26,10 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
 bool conv3x3_resident(const sg_conv2d_params& p);       // eligible and narrow (<= 64 channels both sides): weights stay in LDS
 int conv3x3_reduce_rows(const sg_conv2d_params& p);   // partial rows per sample of the reduction, for eligible geometries
 
+// Transposed 3x3 stride-2 convolution as one unit-stride contraction over the 2 x 2 input window (sg_convup.hip).
+bool conv_up2_eligible(const sg_conv2d_params& p);
+int conv_up2_launch(const sg_conv2d_params& p, hipStream_t stream);
+
 // Weight gradient of the same geometry (sg_wgrad3x3.hip); sg_conv2d_wgrad dispatches.
 bool wgrad3x3_eligible(const sg_conv2d_wgrad_params& p);
 int wgrad3x3_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);

@@ -49,6 +49,8 @@ CASES = [  # name, n, ci, co, h, w, k, kind, stride, padding
     ('t3x3_up2', 2, 64, 32, 16, 16, 3, 'conv_transpose', 2, 0),
     ('t3x3_up2_pad1', 2, 32, 32, 9, 13, 3, 'conv_transpose', 2, 1),
     ('t3x3_lowres', 4, 64, 64, 4, 4, 3, 'conv_transpose', 2, 0),
+    ('t3x3_up2_wide', 2, 64, 40, 24, 24, 3, 'conv_transpose', 2, 0),    # 49 x 49 output: not a whole number of packets
+    ('t3x3_up2_rect', 3, 96, 72, 19, 40, 3, 'conv_transpose', 2, 0),
 ]
 
 
@@ -214,3 +216,26 @@ def test_conv2d_wgrad_stride2_cropped(shape, dtype):
     want2, = torch.autograd.grad(F.conv2d(x2.double(), wt, stride=2, padding=1), wt, dy2)
     dw2 = cp.conv2d_wgrad(x.to(DEV), dy.to(DEV), 3, 3, stride=2, padding=1, x_scale=xs.to(DEV), g_scale=gs.to(DEV))
     close(dw2, want2, 1e-4, 'scaled')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 64, 40, 24, 24), (3, 96, 72, 19, 40), (2, 32, 8, 33, 16), (1, 128, 64, 8, 64)],
+                         ids=['64to40', '96to72', '32to8', '128to64'])
+def test_conv2d_transposed_padded_rows(shape, dtype):
+    """The up-sampling call of the training path: 3x3 stride-2 transposed convolution with modulated input whose
+    output rows are padded to whole 16-byte packets (zero columns): the one-contraction up-sampling kernel."""
+    from ga_gan_amd import conv2d_plugin as cp
+    n, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(ci * 7 + w)
+    x = torch.randn([n, ci, h, w], generator=g).to(dtype)
+    wt = (torch.randn([ci, co, 3, 3], generator=g) / (ci * 9) ** 0.5).to(dtype)
+    s = torch.rand([n, ci], generator=g) + 0.5
+    plan = cp.plan_conv_transpose(3, 3, stride=2)
+    oh, ow = plan.out_size(h, w)
+    ow_pad = (ow + 7) // 8 * 8
+    y = cp.conv2d(x.to(DEV), plan.pack(wt.to(DEV), transposed_layout=True), plan, co, in_scale=s.to(DEV), out_hw=(oh, ow_pad))
+    xs = (x.float() * s.reshape(n, ci, 1, 1)).to(dtype)
+    want = F.conv_transpose2d(xs.double(), wt.double(), stride=2)
+    assert y.shape == (n, co, oh, ow_pad)
+    close(y[..., :ow], want, 2 * ULP[dtype], 'valid part')
+    assert float(y[..., ow:].abs().max()) == 0, 'padding columns must be zero'

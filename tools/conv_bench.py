@@ -14,6 +14,7 @@ LAYERS = [  # ci, co, h, dtype, kind
     (128, 64, 128, torch.bfloat16, 'up'), (256, 128, 64, torch.bfloat16, 'up'),
     (64, 3, 256, torch.bfloat16, '1x1'), (3, 64, 256, torch.bfloat16, '1x1'),
     (64, 128, 257, torch.bfloat16, 'down'),
+    (128, 64, 128, torch.bfloat16, 'up_t'), (256, 128, 64, torch.bfloat16, 'up_t'), (512, 256, 32, torch.bfloat16, 'up_t'),
     (64, 128, 264, torch.bfloat16, 'down_t'), (128, 256, 136, torch.bfloat16, 'down_t'), (256, 512, 72, torch.bfloat16, 'down_t'),
 ]
 if os.environ.get('ONLY'):
@@ -37,7 +38,10 @@ def timeit(fn, iters=10):
 
 for ci, co, h, dtype, kind in LAYERS:
     out_hw = None
-    if kind == 'down_t':   # as in training: blurred plane of (h - 7) rows, h columns (rows padded to whole packets)
+    if kind == 'up_t':     # as in training: output rows padded to whole packets
+        kind, out_hw = 'up', (2 * h + 1, (2 * h + 1 + 7) // 8 * 8)
+        x = torch.randn([N, ci, h, h], device=DEV).to(dtype)
+    elif kind == 'down_t':   # as in training: blurred plane of (h - 7) rows, h columns (rows padded to whole packets)
         kind, out_hw = 'down', ((h - 8) // 2, (h - 8) // 2)
         x = torch.randn([N, ci, h - 7, h], device=DEV).to(dtype)
     else:
