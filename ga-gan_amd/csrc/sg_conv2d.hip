@@ -62,12 +62,19 @@ template <> struct Mma<float> {
 
 struct Tile {
     int split_k;          // > 1: input-channel chunks are divided over blockIdx.z, partial sums added atomically
-    int tw, th, imgs;     // pixel tile in phase coordinates; tw * th * imgs == 256
-    int tw_shift, th_shift;
+    int tw, th, imgs;     // pixel tile in phase coordinates; tw * th * imgs <= 256 (slots beyond it are idle)
     int lw, lh;           // LDS footprint of one image's tile (pixels)
     int tiles_a, tiles_b, tiles_img;
     int vec_epi;          // epilogue through LDS with 16-byte global accesses (8 pixels of one channel per lane)
 };
+
+// Pixel slot (0..255) of a workgroup -> column, row and image within its tile; ri >= t.imgs marks an idle slot.
+__device__ __forceinline__ void slot_decode(const Tile& t, int slot, int& rb, int& ra, int& ri) {
+    rb = slot % t.tw;
+    const int q = slot / t.tw;
+    ra = q % t.th;
+    ri = q / t.th;
+}
 
 
 // Copy the footprint [imgs][lh][lw] (top-left input pixel (iy0, ix0), images img0..) of channels
@@ -247,10 +254,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     int b_addr[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int slot = wave * 64 + j * 16 + lrow;
-        const int rb = slot & (t.tw - 1);
-        const int ra = (slot >> t.tw_shift) & (t.th - 1);
-        const int ri = slot >> (t.tw_shift + t.th_shift);
+        int rb, ra, ri;
+        slot_decode(t, wave * 64 + j * 16 + lrow, rb, ra, ri);
+        if (ri >= t.imgs) rb = ra = ri = 0;   // idle slot: any staged pixel will do, its products are dropped
         b_addr[j] = ((ri * lh + ra * p.in_step) * lw + rb * p.in_step) * kPitch + lgrp * 16;
     }
     const int a_addr = lrow * kPitch + lgrp * 16;
@@ -330,11 +336,10 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         for (int it = 0; it < 2 * M_TILES; it++) {
             const int cblk = it % M_TILES, half = it / M_TILES;
             const int chl = cblk * 16 + lrow, ch = m0 + chl;
-            const int slot = wave * 64 + half * 32 + lgrp * 8;
-            const int b = b0 + (slot & (t.tw - 1));
-            const int a = a0 + ((slot >> t.tw_shift) & (t.th - 1));
-            const int n = img0 + (slot >> (t.tw_shift + t.th_shift));
-            if (ch >= p.co || a >= AH || b >= AW || n >= p.n) continue;
+            int rb, ra, ri;
+            slot_decode(t, wave * 64 + half * 32 + lgrp * 8, rb, ra, ri);
+            const int b = b0 + rb, a = a0 + ra, n = img0 + ri;
+            if (ch >= p.co || a >= AH || b >= AW || n >= p.n || ri >= t.imgs) continue;
             S v[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = s_out[(half * 32 + lgrp * 8 + q) * EP + chl];
@@ -410,10 +415,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         for (int r = 0; r < 4; r++) red[m][r] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int slot = wave * 64 + j * 16 + lrow;
-        const int rb = slot & (t.tw - 1);
-        const int ra = (slot >> t.tw_shift) & (t.th - 1);
-        const int n = img0 + (slot >> (t.tw_shift + t.th_shift));
+        int rb, ra, ri;
+        slot_decode(t, wave * 64 + j * 16 + lrow, rb, ra, ri);
+        const int n = img0 + ri;
         const int a = a0 + ra, b = b0 + rb;
         if (t.imgs > 1) {   // n-tiles of a low-resolution tile belong to different images: flush per n-tile
 #pragma unroll
@@ -421,7 +425,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
 #pragma unroll
                 for (int r = 0; r < 4; r++) red[m][r] = 0;
         }
-        const bool live = !(a >= AH || b >= AW || n >= p.n);
+        const bool live = !(a >= AH || b >= AW || n >= p.n || ri >= t.imgs);
         if (live) {
         const int oy = ph.oy0 + a * p.out_step, ox = ph.ox0 + b * p.out_step;
         S nz = 0;
@@ -449,7 +453,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         }
         }   // live
         if (p.reduce_out && t.imgs > 1) {   // 16 lanes = 16 pixels of one image: shuffle-reduce, one atomic per channel
-            const int n_tile = img0 + ((wave * 64 + j * 16) >> (t.tw_shift + t.th_shift));
+            const int n_tile = img0 + (wave * 64 + j * 16) / (t.tw * t.th);   // tw * th is a multiple of 16 here
 #pragma unroll
             for (int m = 0; m < M_TILES; m++)
 #pragma unroll
@@ -494,7 +498,10 @@ int ilog2(int v) {
     return s;
 }
 
-// Phase-local output extent (largest phase) decides the pixel tile.
+// Phase-local output extent (largest phase) decides the pixel tile: up to 32 columns, then rows, then images, 256
+// pixel slots in all.  Extents below 32 that are no power of two get a tile of exactly their size (a 9 x 12 phase
+// of an up-sampling layer would fill 42% of a 16 x 16 tile), except where the per-image reduction is wanted,
+// whose shuffle groups need tiles of whole 16-pixel groups.
 Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     int AH = 0, AW = 0, max_taps = 0, max_nky = 0, max_nkx = 0;
     for (int i = 0; i < p.num_phases; i++) {
@@ -505,20 +512,25 @@ Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
         max_nky = max(max_nky, ph.nky);
         max_nkx = max(max_nkx, ph.nkx);
     }
+    const bool exact = p.reduce_x == nullptr;
     Tile t;
     t.split_k = 1;
     t.vec_epi = 0;
     t.tw = 32;
     while (t.tw > 1 && t.tw / 2 >= AW) t.tw /= 2;              // smallest power of two covering AW, at most 32
+    if (exact && AW < t.tw) t.tw = AW;
     int rest = kPixels / t.tw;
     t.th = (p.in_step == 1) ? 8 : 4;
+    if (exact && t.tw < 32) t.th = 16;                          // low resolution: whole images where they fit
     if (t.th > rest) t.th = rest;
-    while (t.th > 1 && t.th / 2 >= AH) t.th /= 2;
-    t.imgs = rest / t.th;
-    t.tw_shift = ilog2(t.tw);
-    t.th_shift = ilog2(t.th);
+    if (exact && AH < t.th) t.th = AH;
+    while (!exact && t.th > 1 && t.th / 2 >= AH) t.th /= 2;
     t.lw = (t.tw - 1) * p.in_step + max_nkx;
-    t.lh = (t.th - 1) * p.in_step + max_nky;
+    for (;; t.th = (t.th + 1) / 2) {                            // whole-image tiles of strided layers can outgrow LDS
+        t.imgs = min(rest / t.th, max(p.n, 1));
+        t.lh = (t.th - 1) * p.in_step + max_nky;
+        if (!exact || t.th == 1 || ((size_t)t.imgs * t.lh * t.lw + (size_t)max_taps * 64) * kPitch <= 144 * 1024) break;
+    }
     t.tiles_b = (AW + t.tw - 1) / t.tw;
     t.tiles_a = (AH + t.th - 1) / t.th;
     t.tiles_img = (p.n + t.imgs - 1) / t.imgs;
@@ -531,36 +543,40 @@ template <class T>
 int launch(const sg_conv2d_params& p, hipStream_t stream) {
     int max_taps = 0;
     Tile t = make_tile(p, &max_taps);
-    // 64 output channels per workgroup, unless that leaves most of the 256 CUs without a workgroup
-    const int64_t tiles_px = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img * p.num_phases;
-    const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) >= 256) ? 4 : 1;
-    const int BM = 16 * m_tiles;
-    size_t lds = (size_t)t.imgs * t.lh * t.lw * kPitch + (size_t)max_taps * BM * kPitch;
-    SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
     const int64_t tiles = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img;
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     // Low-resolution float layers: few pixel tiles and a long K loop.  Without an epilogue the sum over input
     // channels can be divided over workgroups that add into a zeroed output.
-    t.split_k = 1;
+    constexpr int KCH = kChunkBytes / (int)sizeof(T);
+    const int chunks = (p.ci + KCH - 1) / KCH;
     const bool plain = !p.in_scale && !p.out_scale && !p.bias && !p.noise && p.act == 1 && p.gain == 1.f && p.clamp < 0 &&
                        !p.reduce_out;
-    if (sizeof(T) == 4 && plain) {
-        constexpr int KCH = kChunkBytes / (int)sizeof(T);
-        const int64_t blocks = tiles * ((p.co + BM - 1) / BM) * p.num_phases;
-        const int chunks = (p.ci + KCH - 1) / KCH;
-        while (t.split_k < 8 && blocks * t.split_k < 512 && chunks / (t.split_k * 2) >= 4) t.split_k *= 2;
+    int max_split = 1;
+    if (sizeof(T) == 4 && plain)
+        while (max_split < 16 && chunks / (max_split * 2) >= 2) max_split *= 2;
+    // 64 output channels per workgroup (every staged pixel then feeds four times the multiplies), unless that
+    // leaves most of the 256 CUs without a workgroup even with the channel sum divided
+    const int64_t tiles_px = tiles * p.num_phases;
+    const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) * max_split >= 256) ? 4 : 1;
+    const int BM = 16 * m_tiles;
+    size_t lds = (size_t)t.imgs * t.lh * t.lw * kPitch + (size_t)max_taps * BM * kPitch;
+    SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
+    t.split_k = 1;
+    {
+        const int64_t blocks = tiles_px * ((p.co + BM - 1) / BM);
+        while (t.split_k < max_split && blocks * t.split_k < 512) t.split_k *= 2;
         if (t.split_k > 1) {
             // (a kernel rather than hipMemsetAsync: memset nodes recorded into a HIP graph were seen to act on
             // the first replay only)
             const size_t words = (size_t)p.n * p.co * p.oh * p.ow * sizeof(T) / 4;
-            const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 4096);
-            hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned*)p.y, words);
+            const unsigned zblocks = (unsigned)std::min<size_t>((words + 255) / 256, 4096);
+            hipLaunchKernelGGL(zero_words_kernel, dim3(zblocks), dim3(256), 0, stream, (unsigned*)p.y, words);
             if (int rc = check_launch("sg_conv2d (zero)")) return rc;
         }
     }
     // Wide epilogue: whole 8-pixel packets of a row must be addressable with aligned 16-byte accesses.
     t.vec_epi = t.split_k == 1 && p.out_step == 1 && p.num_phases == 1 && p.phase[0].oy0 == 0 && p.phase[0].ox0 == 0 &&
-                p.ow % 8 == 0 && t.tw >= 8 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
+                p.ow % 8 == 0 && t.tw % 8 == 0 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
                 (!p.reduce_out || aligned16(p.reduce_x));
     if (t.vec_epi) lds = std::max(lds, (size_t)kPixels * (BM + 4) * sizeof(float));
     dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)(p.num_phases * t.split_k));
@@ -635,9 +651,8 @@ __global__ void __launch_bounds__(kThreads) conv2d_wgrad_kernel(sg_conv2d_wgrad_
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
             const int slot = HALF ? (wave * 64 + ks * 32 + lgrp * 8 + hf * 4 + (lrow >> 2)) : (wave * 64 + ks * 4 + lgrp);
-            const int rb = slot & (t.tw - 1);
-            const int ra = (slot >> t.tw_shift) & (t.th - 1);
-            const int ri = slot >> (t.tw_shift + t.th_shift);
+            int rb, ra, ri;
+            slot_decode(t, slot, rb, ra, ri);
             const int chan = HALF ? (lrow & 3) * 8 : lrow * 4;
             gx_off[ks][hf] = ((ri * lh + ra * p.step) * lw + rb * p.step) * kPitch + chan;
             gg_off[ks][hf] = slot * kPitch + chan;
@@ -713,8 +728,6 @@ int launch_wgrad(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
     if (t.th > rest) t.th = rest;
     while (t.th > 1 && t.th / 2 >= p.gh) t.th /= 2;
     t.imgs = rest / t.th;
-    t.tw_shift = ilog2(t.tw);
-    t.th_shift = ilog2(t.th);
     t.lw = (t.tw - 1) * p.step + p.nkx;
     t.lh = (t.th - 1) * p.step + p.nky;
     t.tiles_b = (p.gw + t.tw - 1) / t.tw;

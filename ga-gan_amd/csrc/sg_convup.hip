@@ -29,7 +29,7 @@ constexpr int TW = 32, TH = 8;            // input-grid tile
 constexpr int KCH = 32;                   // input channels per chunk
 constexpr int BCO = 32;                   // output channels per workgroup (x 4 phases = 128 GEMM columns)
 constexpr int kRow = 64;
-constexpr int LH = TH + 1, LW = TW + 1;   // footprint: rows a0-1 .. a0+7, columns b0-1 .. b0+31
+constexpr int LH = TH + 1;                // footprint: rows a0-1 .. a0+7, columns b0-1 .. b0+31
 constexpr int NV = 5;                     // packets b0-8 .. b0+31
 constexpr int LWP = NV * 8;
 constexpr int PX_COL = 7;                 // column of input b0-1 inside the staged row

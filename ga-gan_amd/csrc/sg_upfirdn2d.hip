@@ -76,6 +76,20 @@ __global__ void __launch_bounds__(256) upfirdn2d_generic_kernel(sg_upfirdn2d_par
     }
 }
 
+// Workgroups of a (tiles, slots) grid are handed to the eight XCDs round-robin in launch order (x fastest), and
+// every XCD has its own L2.  With slots a multiple of 8 this renumbers them so that all tiles of a plane slot run
+// on one XCD, close in time: the halo that neighbouring tiles share then comes out of that L2, not over the
+// fabric a second time.
+__device__ __forceinline__ void plane_major_block(int& tile, int& slot) {
+    tile = blockIdx.x;
+    slot = blockIdx.y;
+    if ((gridDim.y & 7) != 0) return;
+    const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = id & 7, j = id >> 3;
+    tile = j % gridDim.x;
+    slot = (j / gridDim.x) * 8 + xcd;
+}
+
 // ---------------------------------------------------------------------------
 // Tiled kernel.  FW / FH are the tap counts the code is unrolled for (the actual
 // filter may be smaller; missing taps are zero) and must be multiples of UPX / UPY.
@@ -105,8 +119,10 @@ __global__ void __launch_bounds__(256) upfirdn2d_tiled_kernel(sg_upfirdn2d_param
     }
 
     // blockIdx.x enumerates (tile_x, tile_y); blockIdx.y strides over the n*c planes.
-    const int tile_x = blockIdx.x % tiles_x;
-    const int tile_y = blockIdx.x / tiles_x;
+    int tile, slot;
+    plane_major_block(tile, slot);
+    const int tile_x = tile % tiles_x;
+    const int tile_y = tile / tiles_x;
     const int out_x0 = tile_x * TILE_W;
     const int out_y0 = tile_y * TILE_H;
     const int mid_x0 = out_x0 * DOWNX + UPX - 1 - p.pad_x0;
@@ -115,7 +131,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_tiled_kernel(sg_upfirdn2d_param
     const int in_y0 = floor_div(mid_y0, UPY);
     const int planes = p.in_n * p.in_c;
 
-    for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    for (int plane = slot; plane < planes; plane += gridDim.y) {
         const int n = plane / p.in_c;
         const int c = plane - n * p.in_c;
         const T* xp = x + (int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c;
@@ -162,8 +178,9 @@ int launch_tiled(const sg_upfirdn2d_params& p, hipStream_t stream) {
     int64_t gy = planes;
     const int64_t want = 4096;
     if (tiles * gy > want) gy = (want + tiles - 1) / tiles;
-    if (gy > 65535) gy = 65535;
+    if (gy > 65528) gy = 65528;
     if (gy < 1) gy = 1;
+    if (gy > 8) gy = (gy + 7) / 8 * 8;   // whole groups of eight plane slots: see plane_major_block
     hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UPX, UPY, DOWNX, DOWNY, FW, FH, TILE_W, TILE_H>),
                        dim3((unsigned)tiles, (unsigned)gy), dim3(256), 0, stream, p, tiles_x, tiles_y);
     return check_launch("sg_upfirdn2d (tiled)");
@@ -196,7 +213,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
         }
         s_f[tid] = v * p.gain;
     }
-    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    int tile, slot;
+    plane_major_block(tile, slot);
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const int out_x0 = tile_x * TW, out_y0 = tile_y * TH;
     const int in_x0 = out_x0 - p.pad_x0, in_y0 = out_y0 - p.pad_y0;
     // aligned packets that cover [in_x0, in_x0 + IN_W)
@@ -209,7 +228,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
     const int planes = p.in_n * p.in_c;
     const int lx = (tid & 7) * 8, ly = tid >> 3;   // this lane's 8 outputs: row ly, columns lx .. lx+7
 
-    for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    for (int plane = slot; plane < planes; plane += gridDim.y) {
         const int n = plane / p.in_c, c = plane - n * p.in_c;
         const T* xp = x + (int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c;
         T* yp = y + (int64_t)n * p.out_stride_n + (int64_t)c * p.out_stride_c;
@@ -292,8 +311,9 @@ int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream, const sg_epil
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
     int64_t gy = planes;
     if (tiles * gy > 8192) gy = (8192 + tiles - 1) / tiles;
-    if (gy > 65535) gy = 65535;
+    if (gy > 65528) gy = 65528;
     if (gy < 1) gy = 1;
+    if (gy > 8) gy = (gy + 7) / 8 * 8;   // whole groups of eight plane slots: see plane_major_block
     sg_epilogue e = {};
     if (ep) e = *ep;
     hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T>), dim3((unsigned)tiles, (unsigned)gy), dim3(256), 0, stream, p, tiles_x, tiles_y, e,

@@ -17,6 +17,11 @@ LAYERS = [  # ci, co, h, dtype, kind
     (128, 64, 128, torch.bfloat16, 'up_t'), (256, 128, 64, torch.bfloat16, 'up_t'), (512, 256, 32, torch.bfloat16, 'up_t'),
     (64, 128, 264, torch.bfloat16, 'down_t'), (128, 256, 136, torch.bfloat16, 'down_t'), (256, 512, 72, torch.bfloat16, 'down_t'),
 ]
+if os.environ.get('LOWRES'):   # the float32 layers of a 256 x 256 network
+    f = torch.float32
+    LAYERS = [(512, 512, 16, f, 'conv'), (512, 512, 8, f, 'conv'), (512, 512, 4, f, 'conv'), (512, 512, 8, f, 'up_t'),
+              (512, 512, 4, f, 'up_t'), (512, 512, 24, f, 'down_t'), (512, 512, 16, f, 'down_t'), (512, 512, 16, f, 'up'),
+              (512, 512, 8, f, 'up'), (512, 512, 4, f, 'up')]
 if os.environ.get('ONLY'):
     LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
 if os.environ.get('BIG'):
