@@ -204,8 +204,8 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None):
         label = ''
         if _lib.profiling():
             name = _lib.lib().sg_conv2d_wgrad_kernel(ctypes.byref(p)).decode()
-            taps = '' if name == 'wgrad3x3_kernel' else f',{1 if kh * kw <= 1 else 4 if kh * kw <= 4 else 9}'
-            label = f'{name}<{_DTYPE_NAME[x.dtype]}{taps}>'
+            taps = '' if name in ('wgrad3x3_kernel', 'wgrad_f32_kernel') else f',{1 if kh * kw <= 1 else 4 if kh * kw <= 4 else 9}'
+            label = f'{name}<{_DTYPE_NAME[x.dtype]}{taps}>' if name != 'wgrad_f32_kernel' else name
         if _DETAIL and label:
             label += f' k{kh} {cx}->{cg} g{gh}x{gw} step{stride} n{n}'
         _lib.launch('sg_conv2d_wgrad', p, x, label, _lib.nbytes(x, g), flops=2.0 * n * cg * cx * kh * kw * gh * gw)

@@ -800,6 +800,7 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->g && p->dw, SG_ERR_NULL_POINTER, "conv2d_wgrad: x, g and dw must not be NULL");
     if (wgrad3x3_eligible(*p)) return wgrad3x3_launch(*p, (hipStream_t)stream);
+    if (wgrad_f32_eligible(*p)) return wgrad_f32_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
         case SG_F32: return launch_wgrad<float>(*p, (hipStream_t)stream);
         case SG_F16: return launch_wgrad<__half>(*p, (hipStream_t)stream);
@@ -825,5 +826,6 @@ extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
 
 extern "C" const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p) {
     if (p == nullptr) return "";
-    return sg::wgrad3x3_eligible(*p) ? "wgrad3x3_kernel" : "conv2d_wgrad_kernel";
+    if (sg::wgrad3x3_eligible(*p)) return "wgrad3x3_kernel";
+    return sg::wgrad_f32_eligible(*p) ? "wgrad_f32_kernel" : "conv2d_wgrad_kernel";
 }

@@ -230,8 +230,10 @@ int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
 int sg_conv2d_reduce_rows(const sg_conv2d_params* p);
 
 /* Name of the device kernel sg_conv2d runs for this geometry (the symbol a profiler reports, without template
- * arguments): "conv3x3_kernel" for 16-bit 3x3 unit-stride convolutions of more than 64 input channels whose rows
- * are whole aligned packets, "conv2d_mfma_kernel" otherwise.  Static storage. */
+ * arguments).  For 16-bit tensors whose rows are whole aligned packets: "conv3x3_kernel" (3x3, output step 1,
+ * input step 1 or 2), "conv3x3_resident_kernel" (the same with at most 64 channels on both sides: the weights
+ * stay in LDS), "conv_up2_kernel" (3x3 transposed, stride 2, no epilogue); "conv2d_mfma_kernel" otherwise.
+ * Static storage. */
 const char* sg_conv2d_kernel(const sg_conv2d_params* p);
 
 /* ---------------------------------------------------------------------------
@@ -260,9 +262,9 @@ typedef struct sg_conv2d_wgrad_params {
 
 int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stream);
 
-/* Name of the device kernel sg_conv2d_wgrad runs for this geometry: "wgrad3x3_kernel" (16-bit, 3x3, unit stride,
- * at least 32 channels on both sides, rows of whole packets, gradient planes of 8 x 32 pixels or more) or
- * "conv2d_wgrad_kernel".  Static storage. */
+/* Name of the device kernel sg_conv2d_wgrad runs for this geometry: "wgrad3x3_kernel" (16-bit, 3x3, step 1 or 2,
+ * at least 32 channels on both sides, rows of whole packets, gradient planes 32 pixels wide or more),
+ * "wgrad_f32_kernel" (float32, 1x1 or 3x3, at least 32 channels on both sides) or "conv2d_wgrad_kernel".  Static storage. */
 const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p);
 
 #ifdef __cplusplus

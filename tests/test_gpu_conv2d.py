@@ -149,6 +149,10 @@ WGRAD_CASES = [  # name, n, ci, co, h, w, k, stride, padding
     ('1x1_fromrgb', 3, 3, 64, 32, 32, 1, 1, 0),
     ('3x3_stride2', 2, 32, 64, 33, 33, 3, 2, 0),
     ('3x3_nopad', 2, 32, 32, 18, 18, 3, 1, 0),
+    ('3x3_lowres_wide', 5, 136, 72, 16, 16, 3, 1, 1),          # float32: 64 x 64 blocks, ragged channel blocks
+    ('3x3_stride2_lowres', 9, 64, 80, 17, 24, 3, 2, 0),
+    ('3x3_odd_width', 3, 48, 40, 9, 11, 3, 1, 1),               # rows that are no whole packets: scalar staging
+    ('1x1_lowres', 6, 96, 64, 8, 8, 1, 1, 0),
 ]
 
 

@@ -23,6 +23,8 @@ def timeit(fn, iters=10):
 
 
 LAYERS += [(64, 128, -264, torch.bfloat16), (128, 256, -136, torch.bfloat16), (256, 512, -72, torch.bfloat16)]   # h < 0: stride 2, input h x h
+if os.environ.get('ONLY'):
+    LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
 for ci, co, h, dtype in LAYERS:
     stride = 1
     if h < 0:
