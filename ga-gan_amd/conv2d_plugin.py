@@ -8,6 +8,7 @@ import os
 import torch
 
 from . import _lib
+from .torch_utils import memo
 
 
 class Phase(ctypes.Structure):
@@ -37,10 +38,14 @@ class Plan:
         self.in_step, self.out_step = in_step, out_step
         self.phases = phases
         self.out_size = out_size          # (h, w) -> (oh, ow)
+        self.key = (kind, kh, kw, in_step, out_step, tuple((p[4], p[5], tuple(p[6]), tuple(p[7])) for p in phases))
 
     def pack(self, w, transposed_layout=False):
         """w [co, ci, kh, kw] (or [ci, co, kh, kw] when transposed_layout) -> flat packed
-        [phase][ky][kx][co][ci] in w's dtype."""
+        [phase][ky][kx][co][ci] in w's dtype.  Packed once per plan for a weight tensor that is a constant."""
+        return memo.memo(w, ('pack', self.key, transposed_layout), lambda: self._pack(w, transposed_layout))
+
+    def _pack(self, w, transposed_layout):
         if transposed_layout:
             w = w.transpose(0, 1)
         parts = []

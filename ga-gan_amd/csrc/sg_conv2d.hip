@@ -22,6 +22,16 @@
 // Pixel rows are padded to 80 bytes in LDS so that the 16 lanes of a read group fall
 // on different 16-byte bank slots.  Accumulation is float; the epilogue runs on the
 // accumulators and stores once.
+//
+// float32 tensors run on the bf16 matrix instruction as well: a float is the exact sum of
+// three bf16 values (its 24 significant bits cut into three runs of 8), both operands are
+// staged to LDS as three such planes, and a product is accumulated from the six partial
+// products whose weight is at least 2^-16 of the leading one (a0 b0, a0 b1, a1 b0, a0 b2,
+// a1 b1, a2 b0; every one of them exact in the float accumulator's input, the three dropped
+// ones are below 2^-23 of the product, i.e. below float rounding).  Six 16x16x32 bf16
+// instructions take 96 cycles per 32 channels where eight 16x16x4 float ones take 256.  A
+// chunk is 32 channels (3 x 64 bytes per pixel row, pitch 208); the weight chunk is staged
+// three taps at a time so that the tile fits LDS.
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
@@ -38,6 +48,10 @@ constexpr int kPitch = 80;        // bytes per LDS pixel row: 64 payload + 16 pa
 constexpr int kChunkBytes = 64;   // K payload per pixel per chunk
 constexpr int kPixels = 256;      // output pixels per workgroup
 constexpr int kThreads = 256;
+constexpr int kPitchSplit = 208;  // bytes per LDS pixel row of a float tensor split into 3 bf16 planes: 3 x 64 + 16 pad
+constexpr int kSplitTaps = 3;     // taps of the weight chunk held in LDS at a time (split float path)
+
+__device__ __forceinline__ int floor_div_i(int a, int b);
 
 template <class T> struct Mma;
 template <> struct Mma<__hip_bfloat16> {
@@ -50,15 +64,138 @@ template <> struct Mma<__half> {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
 };
-template <> struct Mma<float> {
-    // lane group g = lane >> 4 holds channels 4g .. 4g+3 of the chunk for both operands
-    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
-    }
+
+// v = h0 + h1 + h2 exactly, each the leading 8 significant bits of what the previous ones left (bf16 bit patterns).
+// Infinities and NaNs stay in h0 alone.
+__device__ __forceinline__ void split3(float v, unsigned& h0, unsigned& h1, unsigned& h2) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const unsigned u0 = u & 0xffff0000u;
+    float r1 = v - __builtin_bit_cast(float, u0);
+    if ((u & 0x7f800000u) == 0x7f800000u) r1 = 0.f;
+    const unsigned u1 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, u1);
+    h0 = u0 >> 16;
+    h1 = u1 >> 16;
+    h2 = __builtin_bit_cast(unsigned, r2) >> 16;
+}
+
+// The six partial products of the split float path, smallest first.
+__device__ __forceinline__ void mma_split(const uint4 (&a)[3], const uint4 (&b)[3], f32x4_t& c) {
+    using M = Mma<__hip_bfloat16>;
+    M::run(a[2], b[0], c);
+    M::run(a[1], b[1], c);
+    M::run(a[0], b[2], c);
+    M::run(a[1], b[0], c);
+    M::run(a[0], b[1], c);
+    M::run(a[0], b[0], c);
+}
+
+// Split-float form of stage_pixels / stage_pixels_vec: the footprint of 32 channels from c0 on, as three bf16
+// planes per pixel row (plane p at byte p * 64, channel c at 2 c).  An item is one channel pair x VEC
+// consecutive pixels of a row (VEC = 4: one aligned 16-byte packet per channel; VEC = 1: any row length).  The
+// copy is cut into a load half (global memory -> registers, with the two channel scales) and a store half
+// (scale, split, LDS) so that a caller can keep the loads of the next chunk in flight behind its multiplies.
+struct SplitGeom {
+    const float* x;
+    const float* scale;
+    int n_total, c_total, h, w, img0, imgs, iy0, ix0, lh, lw;
+    int vx0, nv, items;
 };
+
+template <int VEC>
+__device__ __forceinline__ SplitGeom split_geom(const float* x, const float* scale, int n_total, int c_total, int h, int w,
+                                                int img0, int imgs, int iy0, int ix0, int lh, int lw) {
+    SplitGeom g{x, scale, n_total, c_total, h, w, img0, imgs, iy0, ix0, lh, lw, 0, 0, 0};
+    g.vx0 = floor_div_i(ix0, VEC);
+    g.nv = floor_div_i(ix0 + lw - 1, VEC) - g.vx0 + 1;
+    g.items = imgs * lh * g.nv * 16;
+    return g;
+}
+
+template <int VEC> struct SplitItem {
+    float va[VEC], vb[VEC];   // channel c and c + 1
+    float s0, s1;
+};
+
+template <int VEC>
+__device__ __forceinline__ void split_item_load(const SplitGeom& g, int c0, int it, SplitItem<VEC>& d) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) d.va[j] = d.vb[j] = 0.f;
+    d.s0 = d.s1 = 1.f;
+    if (it >= g.items) return;
+    const int cg = it & 15;
+    int r = it >> 4;
+    const int v = r % g.nv; r /= g.nv;
+    const int ry = r % g.lh;
+    const int ri = r / g.lh;
+    const int iy = g.iy0 + ry, n = g.img0 + ri, px0 = (g.vx0 + v) * VEC;
+    const int c = c0 + cg * 2;
+    if (!(iy >= 0 && iy < g.h && n < g.n_total && c < g.c_total && px0 >= 0 && px0 < g.w)) return;
+    const int64_t plane = (int64_t)g.h * g.w;
+    const float* src = g.x + ((int64_t)n * g.c_total + c) * plane + (int64_t)iy * g.w + px0;
+    const bool two = c + 1 < g.c_total;
+    if constexpr (VEC == 4) {
+        const float4 fa = *reinterpret_cast<const float4*>(src);
+        d.va[0] = fa.x; d.va[1] = fa.y; d.va[2] = fa.z; d.va[3] = fa.w;
+        if (two) {
+            const float4 fb = *reinterpret_cast<const float4*>(src + plane);
+            d.vb[0] = fb.x; d.vb[1] = fb.y; d.vb[2] = fb.z; d.vb[3] = fb.w;
+        }
+    } else {
+        d.va[0] = src[0];
+        if (two) d.vb[0] = src[plane];
+    }
+    if (g.scale) {
+        d.s0 = g.scale[(int64_t)n * g.c_total + c];
+        d.s1 = two ? g.scale[(int64_t)n * g.c_total + c + 1] : 0.f;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void split_item_store(unsigned char* s_dst, const SplitGeom& g, int it, const SplitItem<VEC>& d) {
+    if (it >= g.items) return;
+    const int cg = it & 15;
+    int r = it >> 4;
+    const int v = r % g.nv; r /= g.nv;   // r = ri * lh + ry
+    unsigned char* row = s_dst + (r * g.lw) * kPitchSplit + cg * 4;
+    const int rx0 = (g.vx0 + v) * VEC - g.ix0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        const int rx = rx0 + j;
+        if (rx < 0 || rx >= g.lw) continue;
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3(d.va[j] * d.s0, a0, a1, a2);
+        split3(d.vb[j] * d.s1, b0, b1, b2);
+        unsigned char* dst = row + rx * kPitchSplit;
+        *reinterpret_cast<unsigned*>(dst) = a0 | (b0 << 16);
+        *reinterpret_cast<unsigned*>(dst + 64) = a1 | (b1 << 16);
+        *reinterpret_cast<unsigned*>(dst + 128) = a2 | (b2 << 16);
+    }
+}
+
+template <int VEC, int THREADS>
+__device__ __forceinline__ void stage_pixels_split(unsigned char* s_dst, const SplitGeom& g, int c0, int first_item) {
+    constexpr int U = 4;   // loads in flight per lane
+    for (int base = first_item + threadIdx.x; base < g.items; base += U * THREADS) {
+        SplitItem<VEC> d[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) split_item_load<VEC>(g, c0, base + u * THREADS, d[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) split_item_store<VEC>(s_dst, g, base + u * THREADS, d[u]);
+    }
+}
+
+// Four consecutive channels of one weight row -> the three bf16 planes of the LDS row (8 bytes each).
+__device__ __forceinline__ void split_weight_store(unsigned char* dst, const float4& v) {
+    unsigned h[4][3];
+    split3(v.x, h[0][0], h[0][1], h[0][2]);
+    split3(v.y, h[1][0], h[1][1], h[1][2]);
+    split3(v.z, h[2][0], h[2][1], h[2][2]);
+    split3(v.w, h[3][0], h[3][1], h[3][2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++)
+        *reinterpret_cast<uint2*>(dst + pl * 64) = make_uint2(h[0][pl] | (h[1][pl] << 16), h[2][pl] | (h[3][pl] << 16));
+}
 
 struct Tile {
     int split_k;          // > 1: input-channel chunks are divided over blockIdx.z, partial sums added atomically
@@ -217,10 +354,20 @@ __device__ __forceinline__ void stage_tile(unsigned char* s_dst, const T* __rest
     else stage_pixels<T>(s_dst, x, scale, n_total, c_total, h, w, c0, img0, imgs, iy0, ix0, lh, lw);
 }
 
+// Threads per workgroup: the float kernel has room for one workgroup per CU (LDS), so it runs eight waves, two
+// per SIMD, each on half of the pixel slots a wave of the 16-bit kernels covers: one wave's LDS traffic and
+// staging arithmetic then overlaps the other's multiplies.
+template <class T> constexpr int conv_threads() { return sizeof(T) == 4 ? 512 : 256; }
+
 template <class T, int M_TILES>
-__global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_params p, Tile t) {
+__global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) conv2d_mfma_kernel(sg_conv2d_params p, Tile t) {
     using S = float;
-    constexpr int KCH = kChunkBytes / (int)sizeof(T);   // channels per chunk
+    constexpr bool SPLIT = sizeof(T) == 4;              // float: three bf16 planes per operand
+    constexpr int THREADS = conv_threads<T>(), WAVES = THREADS / 64;
+    constexpr int NT = kPixels / (16 * WAVES);          // 16-pixel n-tiles per wave: 4 or 2
+    constexpr int WPX = 16 * NT;                        // pixel slots per wave
+    constexpr int KCH = SPLIT ? 32 : kChunkBytes / (int)sizeof(T);   // channels per chunk
+    constexpr int PITCH = SPLIT ? kPitchSplit : kPitch;
     constexpr int BM = 16 * M_TILES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -245,38 +392,168 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     const int iy0 = a0 * p.in_step + ph.dy0, ix0 = b0 * p.in_step + ph.dx0;
 
     unsigned char* s_in = smem;
-    unsigned char* s_w = smem + (size_t)t.imgs * t.lh * t.lw * kPitch;   // sized for the largest phase
+    unsigned char* s_w = smem + (size_t)t.imgs * t.lh * t.lw * PITCH;   // sized for the largest phase
 
     const T* __restrict__ x = (const T*)p.x;
     const T* __restrict__ w = (const T*)p.w + (int64_t)ph.w_offset;
 
     // ---- per-lane pixel slots of the wave's four n-tiles -----------------------------------
-    int b_addr[4];
+    int b_addr[NT];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NT; j++) {
         int rb, ra, ri;
-        slot_decode(t, wave * 64 + j * 16 + lrow, rb, ra, ri);
+        slot_decode(t, wave * WPX + j * 16 + lrow, rb, ra, ri);
         if (ri >= t.imgs) rb = ra = ri = 0;   // idle slot: any staged pixel will do, its products are dropped
-        b_addr[j] = ((ri * lh + ra * p.in_step) * lw + rb * p.in_step) * kPitch + lgrp * 16;
+        b_addr[j] = ((ri * lh + ra * p.in_step) * lw + rb * p.in_step) * PITCH + lgrp * 16;
     }
-    const int a_addr = lrow * kPitch + lgrp * 16;
+    const int a_addr = lrow * PITCH + lgrp * 16;
 
-    f32x4_t acc[M_TILES][4];
+    f32x4_t acc[M_TILES][NT];
 #pragma unroll
     for (int m = 0; m < M_TILES; m++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const bool w_vec = (p.ci % (16 / (int)sizeof(T)) == 0);
+
+    // ---- split float path: multiply the staged taps [g0, g0 + gtaps) of the weight chunk ------------------------
+    auto split_multiply = [&](int g0, int gtaps) {
+        for (int tl = 0; tl < gtaps; tl++) {
+            const int tap = g0 + tl;
+            const int ky = tap / ph.nkx, kx = tap - ky * ph.nkx;
+            uint4 a[M_TILES][3];
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    a[m][pl] = *reinterpret_cast<const uint4*>(s_w + (tl * BM + m * 16) * PITCH + pl * 64 + a_addr);
+            const int tap_off = (ky * lw + kx) * PITCH;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                uint4 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) b[pl] = *reinterpret_cast<const uint4*>(s_in + b_addr[j] + tap_off + pl * 64);
+#pragma unroll
+                for (int m = 0; m < M_TILES; m++) {
+#ifndef SG_ABL_NOMMA
+                    mma_split(a[m], b, acc[m][j]);
+#else
+                    acc[m][j][0] += __builtin_bit_cast(float, a[m][0].x ^ b[0].x ^ a[m][1].y ^ b[1].y ^ a[m][2].z ^ b[2].z);
+#endif
+                }
+            }
+        }
+    };
+
+    bool contracted = false;   // the fast split path below has already run the whole channel loop
+    if constexpr (SPLIT) {
+        // Fast form (rows of whole aligned packets, channel count a multiple of 4): a pipeline over (chunk, tap
+        // group) stages in which the global loads of the next stage - kSplitTaps taps of weights, and the input
+        // footprint when a new chunk begins - are issued into registers before the multiplies of the current
+        // one, and split / written to LDS after them.
+        const bool fast = w_vec && (p.w_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
+        if (fast) {
+            constexpr int W_IT = (kSplitTaps * BM * 8 + THREADS - 1) / THREADS;   // packets of 4 channels per lane
+            constexpr int X_IT = 2048 / THREADS;                                                 // input items per lane held in registers
+            const SplitGeom g = split_geom<4>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw);
+            const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
+            const int c_begin = ksplit * chunks_per_split * KCH;
+            const int c_end = min(p.ci, c_begin + chunks_per_split * KCH);
+            float4 wreg[W_IT];
+            SplitItem<4> xreg[X_IT];
+            auto w_load = [&](int c0, int g0) {
+                const int gtaps = min(kSplitTaps, taps - g0);
+#pragma unroll
+                for (int k = 0; k < W_IT; k++) {
+                    const int e = tid + k * THREADS;
+                    const int q = e & 7, row = e >> 3;
+                    const int o = row % BM, tap = g0 + row / BM;
+                    const int c = c0 + q * 4;
+                    wreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < gtaps * BM * 8 && m0 + o < p.co && c < p.ci)
+                        wreg[k] = *reinterpret_cast<const float4*>(w + ((int64_t)tap * p.co + m0 + o) * p.ci + c);
+                }
+            };
+            auto w_commit = [&](int g0) {
+                const int gtaps = min(kSplitTaps, taps - g0);
+#pragma unroll
+                for (int k = 0; k < W_IT; k++) {
+                    const int e = tid + k * THREADS;
+                    if (e < gtaps * BM * 8) split_weight_store(s_w + (e >> 3) * PITCH + (e & 7) * 8, wreg[k]);
+                }
+            };
+            auto x_load = [&](int c0) {
+#pragma unroll
+                for (int k = 0; k < X_IT; k++) split_item_load<4>(g, c0, tid + k * THREADS, xreg[k]);
+            };
+            auto x_commit = [&](int c0) {
+#pragma unroll
+                for (int k = 0; k < X_IT; k++) split_item_store<4>(s_in, g, tid + k * THREADS, xreg[k]);
+                stage_pixels_split<4, THREADS>(s_in, g, c0, X_IT * THREADS);   // (footprints beyond the register window)
+            };
+            int c0 = c_begin, g0 = 0;
+            bool new_chunk = true;
+            if (c0 < c_end) {
+                w_load(c0, g0);
+                x_load(c0);
+            }
+            while (c0 < c_end) {
+                __syncthreads();   // the previous stage's fragments have been read
+#ifdef SG_ABL_NOCOMMIT
+                if (c0 == c_begin && g0 == 0) {
+#endif
+                if (new_chunk) x_commit(c0);
+                w_commit(g0);
+#ifdef SG_ABL_NOCOMMIT
+                }
+#endif
+                __syncthreads();
+                int nc0 = c0, ng0 = g0 + kSplitTaps;
+                bool next_new = false;
+                if (ng0 >= taps) { ng0 = 0; nc0 = c0 + KCH; next_new = true; }
+#ifndef SG_ABL_NOLOAD
+                if (nc0 < c_end) {
+                    w_load(nc0, ng0);
+                    if (next_new) x_load(nc0);
+                }
+#endif
+                split_multiply(g0, min(kSplitTaps, taps - g0));
+                c0 = nc0; g0 = ng0; new_chunk = next_new;
+            }
+        }
+        contracted = fast;
+    }
     const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
     const int c_begin = ksplit * chunks_per_split * KCH;
-    const int c_end = min(p.ci, c_begin + chunks_per_split * KCH);
+    const int c_end = contracted ? c_begin : min(p.ci, c_begin + chunks_per_split * KCH);
     for (int c0 = c_begin; c0 < c_end; c0 += KCH) {
         __syncthreads();   // everyone is done reading the previous chunk
+        if constexpr (SPLIT) {
+            // (slow form of the split path: rows that are no whole packets, or channel counts that are no multiple of 4)
+            const SplitGeom g = split_geom<1>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw);
+            stage_pixels_split<1, THREADS>(s_in, g, c0, 0);
+            for (int g0 = 0; g0 < taps; g0 += kSplitTaps) {
+                const int gtaps = min(kSplitTaps, taps - g0);
+                if (g0 > 0) __syncthreads();   // the previous group's fragments have been read
+                for (int e = tid; e < gtaps * BM * KCH; e += THREADS) {
+                    const int cc = e % KCH, row = e / KCH;
+                    const int o = row % BM, tap = g0 + row / BM;
+                    float v = 0.f;
+                    if (m0 + o < p.co && c0 + cc < p.ci) v = w[((int64_t)tap * p.co + m0 + o) * p.ci + c0 + cc];
+                    unsigned h0, h1, h2;
+                    split3(v, h0, h1, h2);
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(s_w + row * PITCH + cc * 2);
+                    dst[0] = (unsigned short)h0; dst[32] = (unsigned short)h1; dst[64] = (unsigned short)h2;
+                }
+                __syncthreads();
+                split_multiply(g0, gtaps);
+            }
+        } else {
         stage_tile<T>(s_in, x, p.in_scale, p.n, p.ci, p.h, p.w_in, c0, img0, t.imgs, iy0, ix0, lh, lw);
         // ---- stage the weight chunk: [tap][BM][channel] ----------------------------------------
         if (w_vec) {
-            for (int e = tid; e < taps * BM * 4; e += kThreads) {
+            for (int e = tid; e < taps * BM * 4; e += THREADS) {
                 const int q = e & 3, row = e >> 2;               // row = tap * BM + o
                 const int o = row % BM, tap = row / BM;
                 const int c = c0 + q * (16 / (int)sizeof(T));
@@ -286,7 +563,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
                 *reinterpret_cast<uint4*>(s_w + row * kPitch + q * 16) = v;
             }
         } else {
-            for (int e = tid; e < taps * BM * KCH; e += kThreads) {
+            for (int e = tid; e < taps * BM * KCH; e += THREADS) {
                 const int cc = e % KCH, row = e / KCH;
                 const int o = row % BM, tap = row / BM;
                 T v = Elem<T>::store(0);
@@ -306,13 +583,16 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
                     a[m] = *reinterpret_cast<const uint4*>(s_w + (tap * BM + m * 16) * kPitch + a_addr);
                 const int tap_off = (ky * lw + kx) * kPitch;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < NT; j++) {
                     const uint4 b = *reinterpret_cast<const uint4*>(s_in + b_addr[j] + tap_off);
 #pragma unroll
-                    for (int m = 0; m < M_TILES; m++) Mma<T>::run(a[m], b, acc[m][j]);
+                    for (int m = 0; m < M_TILES; m++) {
+                        if constexpr (!SPLIT) Mma<T>::run(a[m], b, acc[m][j]);
+                    }
                 }
             }
         }
+        }   // !SPLIT
     }
 
     // ---- epilogue, wide form: the accumulators go through LDS as [pixel][channel] floats and come back as
@@ -321,9 +601,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     if (t.vec_epi) {
         constexpr int EP = BM + 4;   // row pitch in floats: the 8 rows of a 16-byte store group fall on all 32 banks
         __syncthreads();             // every wave has left the multiply loop: its LDS is free
-        float* s_out = reinterpret_cast<float*>(smem) + wave * 64 * EP;
+        float* s_out = reinterpret_cast<float*>(smem) + wave * WPX * EP;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NT; j++)
 #pragma unroll
             for (int m = 0; m < M_TILES; m++)
                 *reinterpret_cast<f32x4_t*>(s_out + (j * 16 + lrow) * EP + m * 16 + lgrp * 4) = acc[m][j];
@@ -333,11 +613,11 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
 #pragma unroll
         for (int m = 0; m < M_TILES; m++) red[m] = 0;
 #pragma unroll
-        for (int it = 0; it < 2 * M_TILES; it++) {
+        for (int it = 0; it < (NT / 2) * M_TILES; it++) {
             const int cblk = it % M_TILES, half = it / M_TILES;
             const int chl = cblk * 16 + lrow, ch = m0 + chl;
             int rb, ra, ri;
-            slot_decode(t, wave * 64 + half * 32 + lgrp * 8, rb, ra, ri);
+            slot_decode(t, wave * WPX + half * 32 + lgrp * 8, rb, ra, ri);
             const int b = b0 + rb, a = a0 + ra, n = img0 + ri;
             if (ch >= p.co || a >= AH || b >= AW || n >= p.n || ri >= t.imgs) continue;
             S v[8];
@@ -396,7 +676,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
             }
             __syncthreads();
             if (tid < BM && m0 + tid < p.co && img0 < p.n) {
-                const float r = s_red[tid] + s_red[BM + tid] + s_red[2 * BM + tid] + s_red[3 * BM + tid];
+                float r = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < WAVES; wv++) r += s_red[wv * BM + tid];
                 const int rows = t.tiles_a * t.tiles_b * p.num_phases;
                 const int row = (ta * t.tiles_b + tb) * p.num_phases + phase;
                 p.reduce_out[((int64_t)img0 * rows + row) * p.co + m0 + tid] = r;
@@ -408,15 +690,15 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
     // ---- epilogue: scale, noise, bias, activation, gain, clamp; one store per element ----------
     const S noise_gain = (p.noise && p.noise_gain) ? *p.noise_gain : (S)1;
     T* __restrict__ y = (T*)p.y;
-    S red[M_TILES][4];   // per-lane share of sum_pixels acc * reduce_x
+    S red[M_TILES][4];   // (4 accumulator rows) per-lane share of sum_pixels acc * reduce_x
 #pragma unroll
     for (int m = 0; m < M_TILES; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++) red[m][r] = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NT; j++) {
         int rb, ra, ri;
-        slot_decode(t, wave * 64 + j * 16 + lrow, rb, ra, ri);
+        slot_decode(t, wave * WPX + j * 16 + lrow, rb, ra, ri);
         const int n = img0 + ri;
         const int a = a0 + ra, b = b0 + rb;
         if (t.imgs > 1) {   // n-tiles of a low-resolution tile belong to different images: flush per n-tile
@@ -453,7 +735,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
         }
         }   // live
         if (p.reduce_out && t.imgs > 1) {   // 16 lanes = 16 pixels of one image: shuffle-reduce, one atomic per channel
-            const int n_tile = img0 + (wave * 64 + j * 16) / (t.tw * t.th);   // tw * th is a multiple of 16 here
+            const int n_tile = img0 + (wave * WPX + j * 16) / (t.tw * t.th);   // tw * th is a multiple of 16 here
 #pragma unroll
             for (int m = 0; m < M_TILES; m++)
 #pragma unroll
@@ -480,7 +762,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv2d_mfma_kernel(sg_conv2d_para
             }
         __syncthreads();
         if (tid < BM && m0 + tid < p.co && img0 < p.n) {
-            const float v = s_red[tid] + s_red[BM + tid] + s_red[2 * BM + tid] + s_red[3 * BM + tid];
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; wv++) v += s_red[wv * BM + tid];
             const int rows = t.tiles_a * t.tiles_b * p.num_phases;
             const int row = (ta * t.tiles_b + tb) * p.num_phases + phase;
             p.reduce_out[((int64_t)img0 * rows + row) * p.co + m0 + tid] = v;
@@ -503,6 +787,8 @@ int ilog2(int v) {
 // of an up-sampling layer would fill 42% of a 16 x 16 tile), except where the per-image reduction is wanted,
 // whose shuffle groups need tiles of whole 16-pixel groups.
 Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
+    const bool split = p.dtype == SG_F32;   // LDS rows and weight-chunk rows of the kernel that runs this dtype
+    const size_t pitch = split ? kPitchSplit : kPitch;
     int AH = 0, AW = 0, max_taps = 0, max_nky = 0, max_nkx = 0;
     for (int i = 0; i < p.num_phases; i++) {
         const sg_conv2d_phase& ph = p.phase[i];
@@ -526,10 +812,28 @@ Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     if (exact && AH < t.th) t.th = AH;
     while (!exact && t.th > 1 && t.th / 2 >= AH) t.th /= 2;
     t.lw = (t.tw - 1) * p.in_step + max_nkx;
+    if (split) {
+        // Rows of 208 bytes: pick the rows x images per tile that fill the most pixel slots within the LDS budget
+        // (slots beyond imgs * th * tw idle).  Tiles that feed the per-image reduction keep whole 16-pixel groups.
+        const size_t budget = 152 * 1024 / pitch - (size_t)min(max_taps, kSplitTaps) * 64;
+        int best_th = 1, best_imgs = 1, best_used = 0;
+        for (int th = t.th; th >= 1; th = (th > 1) ? (th + 1) / 2 : 0) {
+            if (!exact && (t.tw * th) % 16 != 0) break;
+            const size_t lh = (size_t)(th - 1) * p.in_step + max_nky;
+            int imgs = min(rest / th, max(p.n, 1));
+            while (imgs > 1 && imgs * lh * t.lw > budget) imgs--;
+            if (imgs * lh * t.lw > budget) continue;
+            if (imgs * th * t.tw > best_used) { best_used = imgs * th * t.tw; best_th = th; best_imgs = imgs; }
+        }
+        t.th = best_th;
+        t.imgs = best_imgs;
+        t.lh = (t.th - 1) * p.in_step + max_nky;
+    } else {
     for (;; t.th = (t.th + 1) / 2) {                            // whole-image tiles of strided layers can outgrow LDS
         t.imgs = min(rest / t.th, max(p.n, 1));
         t.lh = (t.th - 1) * p.in_step + max_nky;
         if (!exact || t.th == 1 || ((size_t)t.imgs * t.lh * t.lw + (size_t)max_taps * 64) * kPitch <= 144 * 1024) break;
+    }
     }
     t.tiles_b = (AW + t.tw - 1) / t.tw;
     t.tiles_a = (AH + t.th - 1) / t.th;
@@ -547,19 +851,21 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     // Low-resolution float layers: few pixel tiles and a long K loop.  Without an epilogue the sum over input
     // channels can be divided over workgroups that add into a zeroed output.
-    constexpr int KCH = kChunkBytes / (int)sizeof(T);
+    constexpr bool SPLIT = sizeof(T) == 4;
+    constexpr int KCH = SPLIT ? 32 : kChunkBytes / (int)sizeof(T);
+    constexpr size_t PITCH = SPLIT ? kPitchSplit : kPitch;
     const int chunks = (p.ci + KCH - 1) / KCH;
     const bool plain = !p.in_scale && !p.out_scale && !p.bias && !p.noise && p.act == 1 && p.gain == 1.f && p.clamp < 0 &&
                        !p.reduce_out;
     int max_split = 1;
     if (sizeof(T) == 4 && plain)
-        while (max_split < 16 && chunks / (max_split * 2) >= 2) max_split *= 2;
+        while (max_split < 16 && chunks / (max_split * 2) >= (SPLIT ? 1 : 2)) max_split *= 2;
     // 64 output channels per workgroup (every staged pixel then feeds four times the multiplies), unless that
     // leaves most of the 256 CUs without a workgroup even with the channel sum divided
     const int64_t tiles_px = tiles * p.num_phases;
     const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) * max_split >= 256) ? 4 : 1;
     const int BM = 16 * m_tiles;
-    size_t lds = (size_t)t.imgs * t.lh * t.lw * kPitch + (size_t)max_taps * BM * kPitch;
+    size_t lds = ((size_t)t.imgs * t.lh * t.lw + (size_t)(SPLIT ? std::min(max_taps, kSplitTaps) : max_taps) * BM) * PITCH;
     SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
     t.split_k = 1;
     {
@@ -585,7 +891,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
         hipError_t e = allow_large_lds((const void*)kernel);
         if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, p, t);
+    hipLaunchKernelGGL(kernel, grid, dim3(conv_threads<T>()), lds, stream, p, t);
     return check_launch("sg_conv2d");
 }
 

@@ -6,6 +6,7 @@ import torch
 from .. import misc
 from . import conv2d_gradfix
 from . import upfirdn2d
+from .. import memo
 from .upfirdn2d import _get_filter_size, _parse_padding
 
 
@@ -20,7 +21,7 @@ def _align_extra(width):
 def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, **extra):
     """`flip_weight=True` is correlation (what conv2d computes), False is true convolution."""
     if not flip_weight:
-        w = w.flip([2, 3])
+        w = memo.memo(w, 'flip', lambda: w.flip([2, 3]))
     op = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
     return op(x, w, stride=stride, padding=padding, groups=groups, **extra)
 
@@ -73,7 +74,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
 
     if up > 1:                                   # transposed strided conv, then blur (and decimate)
         if groups == 1:
-            w = w.transpose(0, 1)
+            w = memo.memo(w, 'T', lambda: w.transpose(0, 1))
         else:
             w = w.reshape(groups, out_channels // groups, in_channels_per_group, kh, kw).transpose(1, 2)
             w = w.reshape(groups * in_channels_per_group, out_channels // groups, kh, kw)

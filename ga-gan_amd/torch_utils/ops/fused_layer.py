@@ -18,6 +18,7 @@ from . import bias_act
 from . import conv2d_gradfix
 from . import fma
 from . import upfirdn2d
+from .. import memo
 from .conv2d_resample import _align_extra
 from .upfirdn2d import _get_filter_size
 
@@ -37,6 +38,10 @@ def supported(x, w, up, down, groups=1):
     if x.dtype == torch.float32 and x.shape[0] * x.shape[2] * x.shape[3] * (up * up) // (down * down) < MIN_FUSED_PIXELS_F32:
         return False
     return (up, down) in ((1, 1), (1, 2)) or ((up, down) == (2, 1) and kh == 3)
+
+
+def _flipped(w):
+    return memo.memo(w, 'flip', lambda: w.flip([2, 3]))
 
 
 def _noise_plane(noise, dtype):
@@ -140,7 +145,8 @@ class _FusedConv(torch.autograd.Function):
             dt = _fir.upfirdn2d(dz, f, 1, 1, 1, 1, fw - px0 - 1, tw - ow + px0, fh - py0 - 1, th - oh + py0, True, 4.0)
             if want_dx:
                 plan = _conv.plan_conv(k, k, stride=2, padding=0)
-                dx = _conv.conv2d(dt, plan.pack(w.transpose(0, 1)), plan, ci, out_scale=styles, out_hw=tuple(x.shape[2:]),
+                packed = memo.memo(w, ('pack^T', plan.key), lambda: plan.pack(w.transpose(0, 1)))
+                dx = _conv.conv2d(dt, packed, plan, ci, out_scale=styles, out_hw=tuple(x.shape[2:]),
                                   reduce_x=x if want_ds else None)
             if need[1]:   # weight of the transposed conv is w^T [ci, co]; exchange the operands' roles
                 dw = _conv.conv2d_wgrad(dt, x, k, k, stride=2, padding=0, g_scale=styles).transpose(0, 1).to(w.dtype)
@@ -177,7 +183,7 @@ def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=N
 
     if up == 1 and down == 1:
         if not flip_weight:
-            w = w.flip([2, 3])
+            w = _flipped(w)
         out_hw = (x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1)
         cfg = ('same', k, 1, pad, out_hw, act, alpha, gain, clamp, None, 0)
     elif down == 2 and up == 1:
@@ -187,7 +193,7 @@ def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=N
         py0 = pad + (fh - down + 1) // 2
         py1 = pad + (fh - down) // 2
         if not flip_weight:
-            w = w.flip([2, 3])
+            w = _flipped(w)
         if k == 1:
             x = upfirdn2d.upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1])
             cfg = ('same', 1, 1, 0, tuple(x.shape[2:]), act, alpha, gain, clamp, None, 0)
@@ -198,7 +204,7 @@ def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=N
             cfg = ('same', k, down, 0, out_hw, act, alpha, gain, clamp, None, 0)
     else:   # up == 2, k == 3: transposed convolution (true convolution when flip_weight is False), then blur
         if flip_weight:
-            w = w.flip([2, 3])
+            w = _flipped(w)
         px0 = pad + (fw + up - 1) // 2 - (k - 1)
         px1 = pad + (fw - up) // 2 - (k - up)
         py0 = pad + (fh + up - 1) // 2 - (k - 1)

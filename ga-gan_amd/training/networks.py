@@ -22,6 +22,7 @@ import re
 import numpy as np
 import torch
 
+from ..torch_utils import memo
 from ..torch_utils import misc
 from ..torch_utils.ops import bias_act
 from ..torch_utils.ops import conv2d_resample
@@ -260,6 +261,20 @@ def weight_to_weight(self, weight):
     return weight
 
 
+def weight_sources(self):
+    """The tensors `weight_to_weight(self, self.weight)` reads."""
+    sources = [self.weight]
+    affine_kind = getattr(self, 'affine_weights_domain_modulation_parametrization', None)
+    conv_kind = getattr(self, 'weights_domain_modulation_parametrization', None)
+    if affine_kind is not None or conv_kind in out_in_decomposition_parametrizations:
+        sources += [getattr(self, name) for name in list(self.weights_offset_out) + list(self.weights_offset_in)]
+    elif conv_kind is not None:
+        sources.append(self.weights_offset)
+    if affine_kind is not None or conv_kind is not None:
+        sources.append(self.ones_weights)
+    return sources
+
+
 # ----------------------------------------------------------------------------
 
 @misc.profiled_function
@@ -289,11 +304,11 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
 
     dcoefs = None
     if demodulate:   # rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + eps) without the [N,O,I,k,k] intermediate
-        dcoefs = (styles.square() @ weight.square().sum(dim=[2, 3]).t() + 1e-8).rsqrt()
+        dcoefs = (styles.square() @ memo.memo(weight, 'wsq^T', lambda: weight.square().sum(dim=[2, 3]).t()) + 1e-8).rsqrt()
 
     if not fused_modconv:
         x = x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)
-        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+        x = conv2d_resample.conv2d_resample(x=x, w=_cast(weight, x.dtype), f=resample_filter, up=up, down=down,
                                             padding=padding, flip_weight=flip_weight)
         if demodulate and noise is not None:
             x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1), noise.to(x.dtype))
@@ -316,6 +331,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     return x
 
 
+def _cast(weight, dtype):
+    return memo.memo(weight, ('cast', dtype), lambda: weight.to(dtype))
+
+
 def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding, resample_filter, demodulate,
                      flip_weight, act, gain, clamp):
     """Training-path modulated convolution + bias/activation as one fused layer (same arithmetic as
@@ -326,8 +345,8 @@ def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
     dcoefs = None
     if demodulate:
-        dcoefs = (styles.square() @ weight.square().sum(dim=[2, 3]).t() + 1e-8).rsqrt()
-    return fused_layer.conv_layer(x, weight.to(x.dtype), f=resample_filter, up=up, padding=padding, flip_weight=flip_weight,
+        dcoefs = (styles.square() @ memo.memo(weight, 'wsq^T', lambda: weight.square().sum(dim=[2, 3]).t()) + 1e-8).rsqrt()
+    return fused_layer.conv_layer(x, _cast(weight, x.dtype), f=resample_filter, up=up, padding=padding, flip_weight=flip_weight,
                                   styles=styles, dcoefs=dcoefs, noise=noise, noise_strength=noise_strength,
                                   bias=bias, act=act, gain=gain, clamp=clamp)
 
@@ -344,12 +363,12 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = weight_to_weight(self, self.weight.to(x.dtype)) * self.weight_gain
-        b = self.bias
-        if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
+        w = memo.derived(self, ('w', x.dtype), weight_sources(self),
+                         lambda: weight_to_weight(self, self.weight.to(x.dtype)) * self.weight_gain)
+        b = None
+        if self.bias is not None:
+            b = memo.derived(self, ('b', x.dtype), [self.bias],
+                             lambda: self.bias.to(x.dtype) * self.bias_gain if self.bias_gain != 1 else self.bias.to(x.dtype))
         if self.activation == 'linear' and b is not None:
             return torch.addmm(b.unsqueeze(0), x, w.t())
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
@@ -381,8 +400,8 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
-        w = (self.weight * self.weight_gain).to(x.dtype)
-        b = self.bias.to(x.dtype) if self.bias is not None else None
+        w = memo.derived(self, ('w', x.dtype), [self.weight], lambda: (self.weight * self.weight_gain).to(x.dtype))
+        b = memo.derived(self, ('b', x.dtype), [self.bias], lambda: self.bias.to(x.dtype)) if self.bias is not None else None
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         if FUSE_LAYERS and self.activation in ('linear', 'lrelu') and fused_layer.supported(x, w, self.up, self.down):
             return fused_layer.conv_layer(x, w, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
@@ -475,17 +494,18 @@ class SynthesisLayer(torch.nn.Module):
         in_resolution = self.resolution // self.up
         misc.assert_shape(x, [None, self.weight.shape[1], in_resolution, in_resolution])
         styles = w_to_s(self, w=w, weight_gain=1.0, **kwargs)
-        weight = weight_to_weight(self, self.weight)
+        weight = memo.derived(self, 'weight', weight_sources(self), lambda: weight_to_weight(self, self.weight))
+        bias = memo.derived(self, ('b', x.dtype), [self.bias], lambda: self.bias.to(x.dtype))
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         if (FUSE_LAYERS and not fused_modconv and self.activation in ('linear', 'lrelu')
-                and fused_layer.supported(x, weight.to(x.dtype), self.up, 1)):
+                and fused_layer.supported(x, _cast(weight, x.dtype), self.up, 1)):
             unit = None
             if self.use_noise and noise_mode == 'random':
                 unit = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
             if self.use_noise and noise_mode == 'const':
                 unit = self.noise_const
             return _modulated_layer(x, weight, styles, unit, self.noise_strength if unit is not None else None,
-                                    self.bias.to(x.dtype), self.up, self.padding, self.resample_filter, True,
+                                    bias, self.up, self.padding, self.resample_filter, True,
                                     (self.up == 1), self.activation, self.act_gain * gain, act_clamp)
         noise = None
         if self.use_noise and noise_mode == 'random':
@@ -495,7 +515,7 @@ class SynthesisLayer(torch.nn.Module):
         x = modulated_conv2d(x=x, weight=weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1),
                              fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
+        return bias_act.bias_act(x, bias, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
 
 
 class ToRGBLayer(torch.nn.Module):
@@ -518,12 +538,13 @@ class ToRGBLayer(torch.nn.Module):
 
     def forward(self, x, w, fused_modconv=True, noise_mode='random', **kwargs):
         styles = w_to_s(self, w=w, weight_gain=self.weight_gain, **kwargs)
-        weight = weight_to_weight(self, self.weight)
-        if FUSE_LAYERS and not fused_modconv and fused_layer.supported(x, weight.to(x.dtype), 1, 1):
-            return _modulated_layer(x, weight, styles, None, None, self.bias.to(x.dtype), 1, 0, None, False, True,
+        weight = memo.derived(self, 'weight', weight_sources(self), lambda: weight_to_weight(self, self.weight))
+        bias = memo.derived(self, ('b', x.dtype), [self.bias], lambda: self.bias.to(x.dtype))
+        if FUSE_LAYERS and not fused_modconv and fused_layer.supported(x, _cast(weight, x.dtype), 1, 1):
+            return _modulated_layer(x, weight, styles, None, None, bias, 1, 0, None, False, True,
                                     'linear', 1.0, self.conv_clamp)
         x = modulated_conv2d(x=x, weight=weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+        return bias_act.bias_act(x, bias, clamp=self.conv_clamp)
 
 
 class SynthesisBlock(torch.nn.Module):
