@@ -21,6 +21,7 @@ import time
 import numpy as np
 import torch
 
+from .. import optim_plugin
 from ..torch_utils import misc
 from ..torch_utils import training_stats
 from ..torch_utils.ops import conv2d_gradfix
@@ -220,13 +221,13 @@ class Trainer:
                                                        ('D', self.D, D_opt_kwargs, D_reg_interval)):
             opt_kwargs = dict(opt_kwargs)
             if reg_interval is None:
-                opt = torch.optim.Adam(module.parameters(), **opt_kwargs)
+                opt = optim_plugin.FusedAdam(module.parameters(), **opt_kwargs)
                 self.phases.append(Phase(name + 'both', module, opt, 1))
             else:   # lazy regularisation: compensate the optimizer for the extra steps
                 mb_ratio = reg_interval / (reg_interval + 1)
                 opt_kwargs['lr'] = opt_kwargs['lr'] * mb_ratio
                 opt_kwargs['betas'] = [beta ** mb_ratio for beta in opt_kwargs['betas']]
-                opt = torch.optim.Adam(module.parameters(), **opt_kwargs)
+                opt = optim_plugin.FusedAdam(module.parameters(), **opt_kwargs)
                 self.phases.append(Phase(name + 'main', module, opt, 1))
                 self.phases.append(Phase(name + 'reg', module, opt, reg_interval))
         self.cur_nimg = 0
@@ -308,10 +309,7 @@ class Trainer:
                 params = [p for p in phase.module.parameters() if p.grad is not None]
                 self.exchanged_bytes += self.reducer(params)
                 if params:
-                    grads = [p.grad for p in params]
-                    for g in grads:
-                        misc.nan_to_num_(g)
-                    phase.opt.step()
+                    phase.opt.step()   # (sanitises the gradients: NaN -> 0, +-Inf -> +-1e5, then Adam; one launch)
             if self.use_graphs and rounds == 1 and phase.name not in self._graphs and params:   # (a phase that does nothing is not recorded)
                 self._capture_phase(phase, phase_real_img[0], phase_real_c[0], phase_gen_z[0], phase_gen_c[0])
 
@@ -322,7 +320,7 @@ class Trainer:
             ema_beta = 0.5 ** (self.batch_size / max(ema_nimg, 1e-8))
             with torch.no_grad():
                 ema_params, params = list(self.G_ema.parameters()), list(self.G.parameters())
-                torch._foreach_lerp_(ema_params, params, 1 - ema_beta)     # == p.lerp(p_ema, ema_beta)
+                optim_plugin.ema_(ema_params, params, ema_beta)            # p_ema = p.lerp(p_ema, ema_beta)
                 torch._foreach_copy_(list(self.G_ema.buffers()), list(self.G.buffers()))
         self.cur_nimg += self.batch_size
         self.batch_idx += 1

@@ -267,6 +267,53 @@ int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stream);
  * "wgrad_f32_kernel" (float32, 1x1 or 3x3, at least 32 channels on both sides) or "conv2d_wgrad_kernel".  Static storage. */
 const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p);
 
+/* ---------------------------------------------------------------------------
+ * Optimizer step over a list of float32 tensors in one launch.  For every tensor:
+ *   g    = grad with NaN -> 0, +Inf -> +grad_limit, -Inf -> -grad_limit   (written back to grad)
+ *   m    = m + (g - m) * (1 - beta1);   v = v * beta2 + g * g * (1 - beta2)
+ *   p    = p - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * i.e. `param.grad.nan_to_num(0, 1e5, -1e5)` followed by `torch.optim.Adam.step()` without weight decay or
+ * amsgrad, what the reference's loop runs per phase (training/training_loop.py:505-510 with the optimizer of
+ * :303-312; a composite of ~20 list operations plus one kernel per gradient there).  `step` is the number of
+ * updates the tensor has received including this one.  The table is host memory and is consumed before the call
+ * returns; at most SG_OPTIM_MAX_TENSORS tensors per call (the caller cuts longer lists).
+ */
+#define SG_OPTIM_MAX_TENSORS 64
+
+typedef struct sg_adam_tensor {
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    int32_t step;
+} sg_adam_tensor;
+
+typedef struct sg_adam_params {
+    const sg_adam_tensor* tensors; /* host array [count] */
+    int32_t count;
+    float lr, beta1, beta2, eps;
+    float grad_limit; /* 1e5 in the reference */
+} sg_adam_params;
+
+int sg_adam_step(const sg_adam_params* p, sg_stream_t stream);
+
+/* dst = src + beta * (dst - src) over a list of float32 tensors in one launch: the moving average of the generator
+ * weights, `p_ema.copy_(p.lerp(p_ema, ema_beta))` with dst = p_ema, src = p (training/training_loop.py:516-521). */
+typedef struct sg_lerp_tensor {
+    float* dst;
+    const float* src;
+    int64_t numel;
+} sg_lerp_tensor;
+
+typedef struct sg_lerp_params {
+    const sg_lerp_tensor* tensors; /* host array [count] */
+    int32_t count;
+    float beta;
+} sg_lerp_params;
+
+int sg_lerp_multi(const sg_lerp_params* p, sg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

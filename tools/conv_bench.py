@@ -22,6 +22,8 @@ if os.environ.get('LOWRES'):   # the float32 layers of a 256 x 256 network
     LAYERS = [(512, 512, 16, f, 'conv'), (512, 512, 8, f, 'conv'), (512, 512, 4, f, 'conv'), (512, 512, 8, f, 'up_t'),
               (512, 512, 4, f, 'up_t'), (512, 512, 24, f, 'down_t'), (512, 512, 16, f, 'down_t'), (512, 512, 16, f, 'up'),
               (512, 512, 8, f, 'up'), (512, 512, 4, f, 'up')]
+if os.environ.get('F32BIG'):   # the float32 layers of a 1024 x 1024 network (N=16)
+    LAYERS = [(512, 512, 64, torch.float32, 'conv'), (512, 512, 32, torch.float32, 'conv'), (512, 512, 32, torch.float32, 'up_t'), (512, 512, 72, torch.float32, 'down_t')]
 if os.environ.get('ONLY'):
     LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
 if os.environ.get('BIG'):
