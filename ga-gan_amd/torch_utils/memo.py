@@ -20,10 +20,10 @@ import torch
 enabled = True
 
 
-def _bypass(sources):
+def _bypass(sources, values_only=False):
     if not enabled:
         return True
-    if torch.is_grad_enabled() and any(s.requires_grad for s in sources):
+    if not values_only and torch.is_grad_enabled() and any(s.requires_grad for s in sources):
         return True
     # Inside a stream capture every tensor lives in the graph's pool and is rewritten by each replay;
     # a value cached outside would go stale when the parameters change between replays.
@@ -54,9 +54,22 @@ def memo(t, key, fn):
     return hit
 
 
-def derived(owner, key, sources, fn):
+def share(alias, base):
+    """Let `alias` (a view of the constant `base` made for one autograd graph) use base's memoised values."""
+    cache = getattr(base, '_sg_memo', None)
+    if cache is not None:
+        alias._sg_memo = cache
+    return alias
+
+
+def derived(owner, key, sources, fn, values_only=False):
+    """`values_only`: the caller attaches the gradient itself (an autograd function whose forward value this is),
+    so the entry is served even while a source requires grad."""
     sources = [s for s in sources if s is not None]
-    if _bypass(sources):
+    if _bypass(sources, values_only):
+        if values_only:
+            with torch.no_grad():
+                return fn()
         return fn()
     stamp = tuple((s.data_ptr(), s._version) for s in sources)
     store = owner.__dict__.setdefault('_sg_derived', {})

@@ -73,12 +73,15 @@ class _Conv2d(torch.autograd.Function):
             plan = _plugin.plan_conv_transpose(kh, kw, stride=stride, padding=padding)
             y = _plugin.conv2d(x, plan.pack(weight, transposed_layout=True), plan, weight.shape[1], out_hw=out_hw)
         ctx.save_for_backward(input, weight)
+        ctx.w_memo = getattr(weight, '_sg_memo', None)    # packings memoised on a constant weight (torch_utils/memo.py)
         ctx.cfg = cfg
         return y
 
     @staticmethod
     def backward(ctx, grad_output):
         input, weight = ctx.saved_tensors
+        if ctx.w_memo is not None and not hasattr(weight, '_sg_memo'):
+            weight._sg_memo = ctx.w_memo
         transpose, stride, padding, out_hw, kh, kw = ctx.cfg
         grad_input = grad_weight = None
         if ctx.needs_input_grad[0]:

@@ -96,12 +96,15 @@ class _FusedConv(torch.autograd.Function):
         # gradient; a linear, unclamped layer (the residual skips) may then be updated in place by its caller
         keep_y = act != 'linear' or clamp >= 0 or dcoefs is not None
         ctx.save_for_backward(x, w, styles, dcoefs, noise, noise_strength, bias, f, y if keep_y else None)
+        ctx.w_memo = getattr(w, '_sg_memo', None)
         ctx.cfg = cfg
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, styles, dcoefs, noise, noise_strength, bias, f, y = ctx.saved_tensors
+        if ctx.w_memo is not None and not hasattr(w, '_sg_memo'):
+            w._sg_memo = ctx.w_memo
         cfg = ctx.cfg
         mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
         need = ctx.needs_input_grad   # x, w, styles, dcoefs, noise, noise_strength, bias

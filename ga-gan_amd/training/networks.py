@@ -223,7 +223,9 @@ def w_to_s(self, w, weight_gain, style_space_modifications=None, style_space_mod
     elif kind == 'additive_w_space':
         w = w + self.offset * self.offset_mask
 
-    styles = self.affine(w) * weight_gain
+    styles = self.affine(w)
+    if weight_gain != 1:
+        styles = styles * weight_gain
     if saved_styles is not None:
         saved_styles['initial'][self.layer_idx] = styles.detach().cpu()
 
@@ -304,7 +306,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
 
     dcoefs = None
     if demodulate:   # rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + eps) without the [N,O,I,k,k] intermediate
-        dcoefs = (styles.square() @ memo.memo(weight, 'wsq^T', lambda: weight.square().sum(dim=[2, 3]).t()) + 1e-8).rsqrt()
+        dcoefs = _demodulation(styles, weight)
 
     if not fused_modconv:
         x = x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)
@@ -331,6 +333,50 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     return x
 
 
+class _ScaledCast(torch.autograd.Function):
+    """(tensor * gain).to(dtype) with the value taken from the owner's cache of derived tensors, so that a
+    trainable layer evaluated several times between two optimizer steps (the discriminator in Dmain) prepares and
+    packs its weight once; the gradient is gain * g in the parameter's dtype."""
+
+    @staticmethod
+    def forward(ctx, tensor, owner, key, gain, dtype):
+        ctx.gain, ctx.src_dtype = gain, tensor.dtype
+        base = memo.derived(owner, key, [tensor], lambda: _scaled_cast(tensor, gain, dtype), values_only=True)
+        return memo.share(base.view_as(base), base)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.to(ctx.src_dtype)
+        return (g * ctx.gain if ctx.gain != 1 else g), None, None, None, None
+
+
+def _scaled_cast(tensor, gain, dtype):
+    return (tensor * gain).to(dtype) if gain != 1 else tensor.to(dtype)
+
+
+def _prepared(owner, tensor, gain, dtype, key):
+    """(tensor * gain).to(dtype) for a parameter (or buffer) of the module `owner`, once per parameter version."""
+    if torch.is_grad_enabled() and tensor.requires_grad:
+        return _ScaledCast.apply(tensor, owner, (key, dtype), gain, dtype)
+    return memo.derived(owner, (key, dtype), [tensor], lambda: _scaled_cast(tensor, gain, dtype))
+
+
+_EPS = {}
+
+
+def _demodulation(styles, weight):
+    """rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + 1e-8) as one matrix product of s^2 [N, I] with sum_k W^2 [I, O]
+    (kept per weight version), the epsilon folded into the product's additive term."""
+    wsq_t = memo.memo(weight, 'wsq^T', lambda: weight.square().sum(dim=[2, 3]).t())
+    key = (styles.device, styles.dtype)
+    eps = _EPS.get(key)
+    if eps is None:
+        eps = torch.full([1], 1e-8, device=styles.device, dtype=styles.dtype)
+        if not (styles.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _EPS[key] = eps
+    return torch.addmm(eps, styles.square(), wsq_t.to(styles.dtype)).rsqrt()
+
+
 def _cast(weight, dtype):
     return memo.memo(weight, ('cast', dtype), lambda: weight.to(dtype))
 
@@ -345,7 +391,7 @@ def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
     dcoefs = None
     if demodulate:
-        dcoefs = (styles.square() @ memo.memo(weight, 'wsq^T', lambda: weight.square().sum(dim=[2, 3]).t()) + 1e-8).rsqrt()
+        dcoefs = _demodulation(styles, weight)
     return fused_layer.conv_layer(x, _cast(weight, x.dtype), f=resample_filter, up=up, padding=padding, flip_weight=flip_weight,
                                   styles=styles, dcoefs=dcoefs, noise=noise, noise_strength=noise_strength,
                                   bias=bias, act=act, gain=gain, clamp=clamp)
@@ -363,12 +409,12 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = memo.derived(self, ('w', x.dtype), weight_sources(self),
-                         lambda: weight_to_weight(self, self.weight.to(x.dtype)) * self.weight_gain)
-        b = None
-        if self.bias is not None:
-            b = memo.derived(self, ('b', x.dtype), [self.bias],
-                             lambda: self.bias.to(x.dtype) * self.bias_gain if self.bias_gain != 1 else self.bias.to(x.dtype))
+        if getattr(self, 'affine_weights_domain_modulation_parametrization', None) is None:
+            w = _prepared(self, self.weight, self.weight_gain, x.dtype, 'w')
+        else:
+            w = memo.derived(self, ('w', x.dtype), weight_sources(self),
+                             lambda: weight_to_weight(self, self.weight.to(x.dtype)) * self.weight_gain)
+        b = _prepared(self, self.bias, self.bias_gain, x.dtype, 'b') if self.bias is not None else None
         if self.activation == 'linear' and b is not None:
             return torch.addmm(b.unsqueeze(0), x, w.t())
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
@@ -400,8 +446,8 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
-        w = memo.derived(self, ('w', x.dtype), [self.weight], lambda: (self.weight * self.weight_gain).to(x.dtype))
-        b = memo.derived(self, ('b', x.dtype), [self.bias], lambda: self.bias.to(x.dtype)) if self.bias is not None else None
+        w = _prepared(self, self.weight, self.weight_gain, x.dtype, 'w')
+        b = _prepared(self, self.bias, 1, x.dtype, 'b') if self.bias is not None else None
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         if FUSE_LAYERS and self.activation in ('linear', 'lrelu') and fused_layer.supported(x, w, self.up, self.down):
             return fused_layer.conv_layer(x, w, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,

@@ -260,3 +260,32 @@ def test_derived_tensor_cache_follows_parameter_writes():
     assert sum(g is not None and bool(g.abs().sum() > 0) for g in grads) > 20
     G.requires_grad_(False)
     check('after a pass with gradients')
+    # trainable layers serve their prepared weights from the cache as well (values only; the gradient is attached
+    # by the autograd function): gradients with the cache on, twice, against the cache off
+    D.requires_grad_(True)
+    d_params = list(D.parameters())
+
+    def d_grads():
+        img = G(z, c, noise_mode='const').detach()
+        return torch.autograd.grad(D(img, c).sum(), d_params)
+
+    got, got_again = d_grads(), d_grads()
+    memo.enabled = False
+    try:
+        want = d_grads()
+    finally:
+        memo.enabled = True
+    for a, b, w in zip(got, got_again, want):
+        close(a, w, 1e-3, 'D gradient')
+        close(b, w, 1e-3, 'D gradient, cached')
+    with torch.no_grad():
+        for p in d_params:
+            p.mul_(1.01)
+    got = d_grads()
+    memo.enabled = False
+    try:
+        want = d_grads()
+    finally:
+        memo.enabled = True
+    for a, w in zip(got, want):
+        close(a, w, 1e-3, 'D gradient after an update')   # (a stale weight would be off by 1e-2)
