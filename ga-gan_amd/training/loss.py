@@ -1,9 +1,10 @@
 """Training objective of the few-shot loop: non-saturating logistic loss, lazy R1 on
 real images and path-length regularisation, with the reference's phase protocol
 (`accumulate_gradients(phase, real_img, real_c, gen_z, gen_c, sync, gain)`,
-training/loss.py:69-152).  Gradient synchronisation across GPUs is not done here:
-`sync` is recorded on the modules' behalf and the trainer all-reduces the trainable
-gradients after the last accumulation round."""
+training/loss.py:69-152).  Gradient synchronisation across GPUs: where the reference enters `ddp_sync(module, sync)`
+around the forward pass whose backward is the phase's last one, this loss arms `grad_sync`
+(the trainer's GradReducer) right before that backward call, so that gradients are exchanged
+while the rest of the backward pass still runs."""
 import numpy as np
 import torch
 
@@ -32,6 +33,11 @@ class StyleGAN2Loss(Loss):
         self.pl_weight = pl_weight
         self.pl_mean = torch.zeros([], device=device)
         self.synthesis_kwargs = {}      # e.g. dict(noise_mode='const') for deterministic runs
+        self.grad_sync = None           # object with arm(): told when the next backward call's gradients are final
+
+    def _arm(self, sync):
+        if sync and self.grad_sync is not None:
+            self.grad_sync.arm()
 
     def run_G(self, z, c, sync, set_w_requires_grad=False):
         ws = self.G_mapping(z, c)
@@ -70,6 +76,7 @@ class StyleGAN2Loss(Loss):
                 loss_Gmain = torch.nn.functional.softplus(-gen_logits)
                 training_stats.report('Loss/G/loss', loss_Gmain)
             with torch.autograd.profiler.record_function('Gmain_backward'):
+                self._arm(sync and not do_Gpl)   # (Gboth: the path-length pass adds to the same gradients)
                 loss_Gmain.mean().mul(gain).backward()
 
         # Gpl: path-length regularisation on a shrunk batch.
@@ -90,6 +97,7 @@ class StyleGAN2Loss(Loss):
                 loss_Gpl = pl_penalty * self.pl_weight
                 training_stats.report('Loss/G/reg', loss_Gpl)
             with torch.autograd.profiler.record_function('Gpl_backward'):
+                self._arm(sync)
                 (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
 
         # Dmain: minimise logits of generated images.
@@ -126,4 +134,5 @@ class StyleGAN2Loss(Loss):
                     training_stats.report('Loss/r1_penalty', r1_penalty)
                     training_stats.report('Loss/D/reg', loss_Dr1)
             with torch.autograd.profiler.record_function(name + '_backward'):
+                self._arm(sync)                  # (the Dgen pass before it is not final)
                 (real_logits * 0 + loss_Dreal + loss_Dr1).mean().mul(gain).backward()

@@ -135,33 +135,96 @@ def setup_training_options(cfg='paper256', resolution=256, batch_size=None, num_
 class GradReducer:
     """Average the gradients of a parameter list across ranks with as few collectives
     as possible: gradients are packed into one flat buffer per dtype, all-reduced in
-    buckets of `bucket_bytes` (asynchronously, so packing bucket k+1 overlaps the
-    reduction of bucket k on RCCL's stream), and unpacked in place."""
+    buckets of `bucket_bytes` (asynchronously, on RCCL's own stream), and unpacked in place.
+
+    Two ways to drive it:
+      * `reducer(params)` after the backward pass: pack, reduce, unpack;
+      * overlapped with the backward pass (what the trainer does): `attach(params)` once, `arm()`
+        right before the backward call whose gradients are final (the reference synchronises on exactly
+        that call: `sync` in training/loss.py:69-152, misc.ddp_sync), `finish(params)` after it.  While
+        armed, every parameter reports from autograd's post-accumulate hook the moment its gradient is
+        complete; a full bucket is packed and its all-reduce enqueued at once, so the exchange of the
+        layers that finish first runs under the backward pass of the remaining ones.  The discriminator
+        profits most: its 512-channel low-resolution weights - most of its bytes - are the first to
+        finish.  All ranks run the same graph, so buckets form in the same order everywhere.
+    """
 
     def __init__(self, world_size, bucket_bytes=64 << 20, group=None):
         self.world_size = world_size
         self.bucket_bytes = bucket_bytes
         self.group = group
+        self._attached = set()
+        self._armed = False
+        self._bucket, self._bucket_size, self._pending, self._seen = [], 0, [], set()
 
+    # -- after the fact ----------------------------------------------------------
     def __call__(self, params):
         if self.world_size <= 1:
             return 0
         grads = [p.grad for p in params if p.grad is not None]
         if not grads:
             return 0
-        buckets, current, size = [], [], 0
         for g in grads:
-            if current and (size + g.numel() * g.element_size() > self.bucket_bytes or g.dtype != current[0].dtype):
-                buckets.append(current)
-                current, size = [], 0
-            current.append(g)
-            size += g.numel() * g.element_size()
-        buckets.append(current)
-        pending = []
-        for bucket in buckets:
-            flat = torch.cat([g.reshape(-1) for g in bucket])
-            work = torch.distributed.all_reduce(flat, group=self.group, async_op=True)
-            pending.append((work, flat, bucket))
+            self._add(g)
+        return self._drain()
+
+    # -- overlapped with backward ---------------------------------------------------
+    def attach(self, params):
+        """Register the completion hook on every parameter (once; idle until `arm()`)."""
+        if self.world_size <= 1:
+            return
+        for p in params:
+            if id(p) not in self._attached:
+                self._attached.add(id(p))
+                frozen = not p.requires_grad          # (hooks can only be registered on tensors that require grad;
+                p.requires_grad_(True)                #  the hook stays when the flag is switched back)
+                p.register_post_accumulate_grad_hook(self._on_grad_ready)
+                p.requires_grad_(not frozen)
+
+    def arm(self):
+        """The next backward call produces final gradients: exchange them as they complete."""
+        if self.world_size > 1:
+            self._armed = True
+            self._seen = set()
+
+    def _on_grad_ready(self, p):
+        if self._armed and p.grad is not None:
+            self._seen.add(id(p))
+            self._add(p.grad)
+
+    def finish(self, params):
+        """After the armed backward call: exchange what the hooks have not covered (parameters that were
+        not attached, or whose gradient stems from an earlier call only), wait, average, unpack.  Returns
+        the bytes exchanged."""
+        if self.world_size <= 1:
+            return 0
+        armed, self._armed = self._armed, False
+        for p in params:
+            if p.grad is not None and not (armed and id(p) in self._seen):
+                self._add(p.grad)
+        self._seen = set()
+        return self._drain()
+
+    # -- buckets -------------------------------------------------------------------
+    def _add(self, g):
+        if self._bucket and (self._bucket_size + g.numel() * g.element_size() > self.bucket_bytes or g.dtype != self._bucket[0].dtype):
+            self._flush()
+        self._bucket.append(g)
+        self._bucket_size += g.numel() * g.element_size()
+        if self._bucket_size >= self.bucket_bytes:
+            self._flush()
+
+    def _flush(self):
+        if not self._bucket:
+            return
+        bucket, self._bucket, self._bucket_size = self._bucket, [], 0
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        work = torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+        self._pending.append((work, flat, bucket))
+
+    def _drain(self):
+        self._flush()
+        pending, self._pending = self._pending, []
         total = 0
         for work, flat, bucket in pending:
             work.wait()
@@ -216,6 +279,8 @@ class Trainer:
         self.requires_grad_parts = requires_grad_parts or {k: ['all'] for k in
                                                            ('Gboth', 'Gmain', 'Greg', 'Dboth', 'Dmain', 'Dreg')}
         self.reducer = GradReducer(num_gpus)
+        self.reducer.attach(list(self.G.parameters()) + list(self.D.parameters()))
+        self.loss.grad_sync = None if use_graphs else self.reducer   # (a recorded phase exchanges after its replay)
         self.phases = []
         for name, module, opt_kwargs, reg_interval in (('G', self.G, G_opt_kwargs, G_reg_interval),
                                                        ('D', self.D, D_opt_kwargs, D_reg_interval)):
@@ -307,7 +372,7 @@ class Trainer:
                 phase.module.requires_grad_(False)
             with torch.autograd.profiler.record_function(phase.name + '_opt'):
                 params = [p for p in phase.module.parameters() if p.grad is not None]
-                self.exchanged_bytes += self.reducer(params)
+                self.exchanged_bytes += self.reducer.finish(params)
                 if params:
                     phase.opt.step()   # (sanitises the gradients: NaN -> 0, +-Inf -> +-1e5, then Adam; one launch)
             if self.use_graphs and rounds == 1 and phase.name not in self._graphs and params:   # (a phase that does nothing is not recorded)

@@ -56,6 +56,68 @@ def test_grad_reducer_two_ranks_gloo(bucket_bytes):
     assert sorted(results) == [(0, True, True), (1, True, True)]
 
 
+def _rank_overlap(rank, world, port, bucket_bytes, result_queue):
+    """Two backward calls per phase (as Dmain: generated, then real images); the reducer is armed before the second,
+    exchanges from the post-accumulate hooks, and must end with the rank average of the accumulated gradients."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    from ga_gan_amd.training.training_loop import GradReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 3))
+    frozen = torch.nn.Linear(3, 3).requires_grad_(False)   # attached while frozen, takes no part in the phase
+    net.requires_grad_(False)                           # (the trainer attaches to frozen networks and enables parts per phase)
+    extra = torch.nn.Parameter(torch.ones(4))           # not attached: covered by finish()
+    reducer = GradReducer(world, bucket_bytes=bucket_bytes)
+    reducer.attach(list(net.parameters()) + list(frozen.parameters()))
+    net.requires_grad_(True)
+    fired = []
+    for q in net.parameters():
+        q.register_post_accumulate_grad_hook(lambda t: fired.append(len(reducer._pending)))
+    torch.manual_seed(100 + rank)
+    x1, x2 = torch.randn(8, 20), torch.randn(8, 20)
+    ok = True
+    for phase in range(2):                              # hooks stay registered from phase to phase
+        for q in list(net.parameters()) + [extra]:
+            q.grad = None
+        net(x1).square().mean().backward()              # not armed: nothing is exchanged yet
+        ok &= len(reducer._pending) == 0 and not reducer._bucket
+        local_first = [q.grad.clone() for q in net.parameters()]
+        reducer.arm()
+        (net(x2).square().mean() + (extra * (rank + 1)).sum()).backward()
+        in_flight = len(reducer._pending)               # buckets already handed to the backend during backward
+        params = list(net.parameters()) + [extra]
+        local = [q.grad.clone() for q in params]
+        moved = reducer.finish(params)
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, local)
+        for i, q in enumerate(params):
+            mean = sum(g[i] for g in gathered) / world
+            ok &= torch.allclose(q.grad, mean, atol=1e-6)
+        ok &= moved == sum(q.numel() * 4 for q in params)
+        ok &= all(a.abs().sum() > 0 for a in local_first)
+        if bucket_bytes < 1 << 20:
+            ok &= in_flight >= 2                        # small buckets: the exchange started before backward ended
+    ok &= all(q.grad is None for q in frozen.parameters())
+    result_queue.put((rank, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_bytes', [64 << 20, 8192])
+def test_grad_reducer_overlapped_with_backward_two_ranks_gloo(bucket_bytes):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_overlap, args=(r, 2, port, bucket_bytes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
 def test_grad_reducer_single_rank_is_a_no_op():
     from ga_gan_amd.training.training_loop import GradReducer
     p = torch.nn.Parameter(torch.ones(3))
