@@ -43,7 +43,18 @@ if __name__ == '__main__':
     procs = [ctx.Process(target=rank_main, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    import queue
+    res = []
+    while len(res) < len(procs):     # a rank that died never reports: fail at once instead of waiting for it
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                for p in procs:
+                    p.kill()
+                raise SystemExit(f'a rank exited with {dead}')
+    res.sort(key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
     worst = max(abs(res[0][1][n] - res[1][1][n]) / max(abs(res[0][1][n]), 1e-6) for n in res[0][1])
