@@ -11,6 +11,7 @@ namespace sg {
 namespace {
 
 constexpr int kMaxGroup = 64;
+constexpr int kThreads = 1024;   // few workgroups exist (groups x channel sets): each is as wide as the hardware allows
 
 template <class S>
 __device__ __forceinline__ S block_sum(S v, S* scratch) {
@@ -27,9 +28,9 @@ __device__ __forceinline__ S block_sum(S v, S* scratch) {
 
 // grid = (n / g groups, f channel sets); element e of a set runs over (c / f) * hw.
 template <class T, bool BACKWARD>
-__global__ void __launch_bounds__(256) mbstd_kernel(sg_mbstd_params p) {
+__global__ void __launch_bounds__(kThreads) mbstd_kernel(sg_mbstd_params p) {
     using S = typename Elem<T>::acc_t;
-    __shared__ S scratch[256 / kWave];
+    __shared__ S scratch[kThreads / kWave];
     const int groups = p.n / p.g;
     const int m = blockIdx.x, f = blockIdx.y;
     const int cs = p.c / p.f;                 // channels per set
@@ -93,9 +94,9 @@ template <class T>
 int launch(const sg_mbstd_params& p, hipStream_t stream, bool backward) {
     dim3 grid((unsigned)(p.n / p.g), (unsigned)p.f);
     if (backward)
-        hipLaunchKernelGGL((mbstd_kernel<T, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((mbstd_kernel<T, true>), grid, dim3(kThreads), 0, stream, p);
     else
-        hipLaunchKernelGGL((mbstd_kernel<T, false>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((mbstd_kernel<T, false>), grid, dim3(kThreads), 0, stream, p);
     return check_launch(backward ? "sg_mbstd_backward" : "sg_mbstd_forward");
 }
 

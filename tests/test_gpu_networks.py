@@ -276,11 +276,11 @@ def test_derived_tensor_cache_follows_parameter_writes():
     finally:
         memo.enabled = True
     for a, b, w in zip(got, got_again, want):
-        close(a, w, 1e-3, 'D gradient')
-        close(b, w, 1e-3, 'D gradient, cached')
+        close(a, w, 1e-2, 'D gradient')   # (bfloat16 weight gradients: one unit in the last place is 4e-3)
+        close(b, w, 1e-2, 'D gradient, cached')
     with torch.no_grad():
         for p in d_params:
-            p.mul_(1.01)
+            p.mul_(1.5)
     got = d_grads()
     memo.enabled = False
     try:
@@ -288,4 +288,4 @@ def test_derived_tensor_cache_follows_parameter_writes():
     finally:
         memo.enabled = True
     for a, w in zip(got, want):
-        close(a, w, 1e-3, 'D gradient after an update')   # (a stale weight would be off by 1e-2)
+        close(a, w, 1e-2, 'D gradient after an update')   # (a stale weight would be off by tens of percent)
