@@ -65,18 +65,26 @@ template <> struct Mma<__half> {
     }
 };
 
-// v = h0 + h1 + h2 exactly, each the leading 8 significant bits of what the previous ones left (bf16 bit patterns).
-// Infinities and NaNs stay in h0 alone.
+// Two floats a, b -> three dwords p0, p1, p2 of bf16 pairs (a's piece in the low half) with
+// a = a0 + a1 + a2 and b = b0 + b1 + b2 exactly: each piece is the leading 8 significant bits (the upper
+// 16 bits of the float pattern) of what the previous pieces left.  Eleven vector operations per pair.  A
+// non-finite input leaves NaN in the lower pieces (inf - inf), so it poisons the outputs it reaches.
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    constexpr unsigned kUpperHalves = 0x07060302u;   // v_perm_b32: {b[31:16], a[31:16]}
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    p0 = __builtin_amdgcn_perm(ub, ua, kUpperHalves);
+    const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u), rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
+    const unsigned va = __builtin_bit_cast(unsigned, ra), vb = __builtin_bit_cast(unsigned, rb);
+    p1 = __builtin_amdgcn_perm(vb, va, kUpperHalves);
+    const float sa = ra - __builtin_bit_cast(float, va & 0xffff0000u), sb = rb - __builtin_bit_cast(float, vb & 0xffff0000u);
+    p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), kUpperHalves);
+}
+
+// One float -> its three bf16 bit patterns (the scalar staging path).
 __device__ __forceinline__ void split3(float v, unsigned& h0, unsigned& h1, unsigned& h2) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const unsigned u0 = u & 0xffff0000u;
-    float r1 = v - __builtin_bit_cast(float, u0);
-    if ((u & 0x7f800000u) == 0x7f800000u) r1 = 0.f;
-    const unsigned u1 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, u1);
-    h0 = u0 >> 16;
-    h1 = u1 >> 16;
-    h2 = __builtin_bit_cast(unsigned, r2) >> 16;
+    unsigned p0, p1, p2;
+    split3_pair(v, 0.f, p0, p1, p2);
+    h0 = p0 & 0xffffu; h1 = p1 & 0xffffu; h2 = p2 & 0xffffu;
 }
 
 // The six partial products of the split float path, smallest first.
@@ -163,13 +171,12 @@ __device__ __forceinline__ void split_item_store(unsigned char* s_dst, const Spl
     for (int j = 0; j < VEC; j++) {
         const int rx = rx0 + j;
         if (rx < 0 || rx >= g.lw) continue;
-        unsigned a0, a1, a2, b0, b1, b2;
-        split3(d.va[j] * d.s0, a0, a1, a2);
-        split3(d.vb[j] * d.s1, b0, b1, b2);
+        unsigned p0, p1, p2;
+        split3_pair(d.va[j] * d.s0, d.vb[j] * d.s1, p0, p1, p2);
         unsigned char* dst = row + rx * kPitchSplit;
-        *reinterpret_cast<unsigned*>(dst) = a0 | (b0 << 16);
-        *reinterpret_cast<unsigned*>(dst + 64) = a1 | (b1 << 16);
-        *reinterpret_cast<unsigned*>(dst + 128) = a2 | (b2 << 16);
+        *reinterpret_cast<unsigned*>(dst) = p0;
+        *reinterpret_cast<unsigned*>(dst + 64) = p1;
+        *reinterpret_cast<unsigned*>(dst + 128) = p2;
     }
 }
 
@@ -187,14 +194,11 @@ __device__ __forceinline__ void stage_pixels_split(unsigned char* s_dst, const S
 
 // Four consecutive channels of one weight row -> the three bf16 planes of the LDS row (8 bytes each).
 __device__ __forceinline__ void split_weight_store(unsigned char* dst, const float4& v) {
-    unsigned h[4][3];
-    split3(v.x, h[0][0], h[0][1], h[0][2]);
-    split3(v.y, h[1][0], h[1][1], h[1][2]);
-    split3(v.z, h[2][0], h[2][1], h[2][2]);
-    split3(v.w, h[3][0], h[3][1], h[3][2]);
+    unsigned lo[3], hi[3];
+    split3_pair(v.x, v.y, lo[0], lo[1], lo[2]);
+    split3_pair(v.z, v.w, hi[0], hi[1], hi[2]);
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++)
-        *reinterpret_cast<uint2*>(dst + pl * 64) = make_uint2(h[0][pl] | (h[1][pl] << 16), h[2][pl] | (h[3][pl] << 16));
+    for (int pl = 0; pl < 3; pl++) *reinterpret_cast<uint2*>(dst + pl * 64) = make_uint2(lo[pl], hi[pl]);
 }
 
 struct Tile {
