@@ -193,11 +193,16 @@ int launch_tiled(const sg_upfirdn2d_params& p, hipStream_t stream) {
 // 64 x 32 output tile: the 67 x 35 input footprint is fetched with aligned 16-byte packets and
 // kept in LDS as float; every lane then produces 8 consecutive outputs of one row from four
 // 12-wide LDS row segments (three 16-byte reads per row) and writes them with one 16-byte store.
-template <class T>
+template <class T, int SHIFT>   // SHIFT = (first tap column in the LDS image) mod 4
 __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_params p, int tiles_x, int tiles_y, sg_epilogue ep,
-                                                              bool has_ep) {
+                                                              bool has_ep, int vec_in) {
+    // LDS image of a tile: rows of PITCH floats whose column 0 is the aligned 16-byte packet of the input row that
+    // holds the tile's first tap (input column in_x0 sits at column `delta`, the same for every tile since tiles are
+    // 64 wide).  Packets are therefore written whole, as float4 stores (single-float stores at a stride of 8 land
+    // on 4 of the 32 banks), and a lane reads its 11-float window from 4 aligned float4 at the compile-time offset
+    // SHIFT = delta mod 4.
     constexpr int TW = 64, TH = 32, FW = 4, FH = 4;
-    constexpr int IN_W = TW + FW - 1, IN_H = TH + FH - 1, PITCH = 68;
+    constexpr int IN_W = TW + FW - 1, IN_H = TH + FH - 1, PITCH = 84;
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) float s_x[IN_H * PITCH];
     __shared__ float s_f[FH * FW];
@@ -218,15 +223,15 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const int out_x0 = tile_x * TW, out_y0 = tile_y * TH;
     const int in_x0 = out_x0 - p.pad_x0, in_y0 = out_y0 - p.pad_y0;
-    // aligned packets that cover [in_x0, in_x0 + IN_W)
+    // aligned packets that cover [in_x0, in_x0 + IN_W); without vector loads the image starts at in_x0 itself
     const int vx0 = (in_x0 >= 0) ? in_x0 / VEC : -((-in_x0 + VEC - 1) / VEC);
-    const int nv = (in_x0 + IN_W - 1 - vx0 * VEC) / VEC + 1;
-    const bool vec_in = (p.in_stride_h % VEC == 0) && (p.in_stride_c % VEC == 0) && (p.in_stride_n % VEC == 0) &&
-                        (p.in_w % VEC == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    const int delta = vec_in ? in_x0 - vx0 * VEC : 0;
+    const int nv = (delta + IN_W - 1) / VEC + 1;
     const bool vec_out = (p.out_stride_h % VEC == 0) && (p.out_stride_c % VEC == 0) && (p.out_stride_n % VEC == 0) &&
                          ((reinterpret_cast<uintptr_t>(y) & 15u) == 0);
     const int planes = p.in_n * p.in_c;
     const int lx = (tid & 7) * 8, ly = tid >> 3;   // this lane's 8 outputs: row ly, columns lx .. lx+7
+    const int win = lx + (delta & ~3);             // first float4 of the lane's window
 
     for (int plane = slot; plane < planes; plane += gridDim.y) {
         const int n = plane / p.in_c, c = plane - n * p.in_c;
@@ -237,14 +242,17 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
             for (int it = tid; it < IN_H * nv; it += 256) {
                 const int ry = it / nv, v = it - ry * nv;
                 const int iy = in_y0 + ry, px0 = (vx0 + v) * VEC;
-                Pack<T> pk;
-                const bool ok = iy >= 0 && iy < p.in_h && px0 >= 0 && px0 < p.in_w;
-                if (ok) pk = load_pack(xp + (int64_t)iy * p.in_stride_h + px0);
+                float f[VEC];
 #pragma unroll
-                for (int j = 0; j < VEC; j++) {
-                    const int rx = px0 + j - in_x0;
-                    if (rx >= 0 && rx < IN_W) s_x[ry * PITCH + rx] = ok ? (float)Elem<T>::load(pk.v[j]) : 0.f;
+                for (int j = 0; j < VEC; j++) f[j] = 0.f;
+                if (iy >= 0 && iy < p.in_h && px0 >= 0 && px0 < p.in_w) {
+                    const Pack<T> pk = load_pack(xp + (int64_t)iy * p.in_stride_h + px0);
+#pragma unroll
+                    for (int j = 0; j < VEC; j++) f[j] = (float)Elem<T>::load(pk.v[j]);
                 }
+                float4* dst = reinterpret_cast<float4*>(s_x + ry * PITCH + v * VEC);
+#pragma unroll
+                for (int q = 0; q < VEC / 4; q++) dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
             }
         } else {
             for (int it = tid; it < IN_H * IN_W; it += 256) {
@@ -262,14 +270,18 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
         for (int j = 0; j < 8; j++) acc[j] = 0.f;
 #pragma unroll
         for (int fy = 0; fy < FH; fy++) {
-            const float4* row = reinterpret_cast<const float4*>(s_x + (ly + fy) * PITCH + lx);
+            const float4* row = reinterpret_cast<const float4*>(s_x + (ly + fy) * PITCH + win);
             const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            const float in[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            float in[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (SHIFT > 1) {   // the window's last floats lie in a fourth packet
+                const float4 r3 = row[3];
+                in[12] = r3.x; in[13] = r3.y; in[14] = r3.z; in[15] = r3.w;
+            }
 #pragma unroll
             for (int fx = 0; fx < FW; fx++) {
                 const float tap = s_f[fy * FW + fx];
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] += in[j + fx] * tap;
+                for (int j = 0; j < 8; j++) acc[j] += in[j + fx + SHIFT] * tap;
             }
         }
         const int oy = out_y0 + ly, ox = out_x0 + lx;
@@ -316,8 +328,19 @@ int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream, const sg_epil
     if (gy > 8) gy = (gy + 7) / 8 * 8;   // whole groups of eight plane slots: see plane_major_block
     sg_epilogue e = {};
     if (ep) e = *ep;
-    hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T>), dim3((unsigned)tiles, (unsigned)gy), dim3(256), 0, stream, p, tiles_x, tiles_y, e,
-                       ep != nullptr);
+    // Rows of whole aligned packets are loaded as such; the column of the first tap inside its packet is then the
+    // same for every tile (tiles are 64 outputs wide): -pad_x0 modulo the packet length.
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int vec_in = (p.in_stride_h % VEC == 0) && (p.in_stride_c % VEC == 0) && (p.in_stride_n % VEC == 0) &&
+                       (p.in_w % VEC == 0) && aligned16(p.x);
+    const int delta = vec_in ? ((-p.pad_x0) % VEC + VEC) % VEC : 0;
+    const dim3 grid((unsigned)tiles, (unsigned)gy);
+    switch (delta & 3) {
+        case 0: hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T, 0>), grid, dim3(256), 0, stream, p, tiles_x, tiles_y, e, ep != nullptr, vec_in); break;
+        case 1: hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T, 1>), grid, dim3(256), 0, stream, p, tiles_x, tiles_y, e, ep != nullptr, vec_in); break;
+        case 2: hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T, 2>), grid, dim3(256), 0, stream, p, tiles_x, tiles_y, e, ep != nullptr, vec_in); break;
+        default: hipLaunchKernelGGL((upfirdn2d_blur4_kernel<T, 3>), grid, dim3(256), 0, stream, p, tiles_x, tiles_y, e, ep != nullptr, vec_in); break;
+    }
     return check_launch("sg_upfirdn2d (blur)");
 }
 
