@@ -210,3 +210,26 @@ def upfirdn2d_numpy(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1.0):
                     acc += x[:, :, iy, ix] * f[ty, tx]
             y[:, :, oy, ox] = acc * gain
     return y
+
+
+def grid_sample(input, grid):
+    """Bilinear sampling of input [N, C, H, W] at grid [N, Ho, Wo, 2] (x, y in [-1, 1]; zero padding,
+    align_corners=False), written out with gathers so that it is differentiable to any order in the image and the
+    grid.  Restates what the reference's grid_sample_gradfix computes
+    (DissimilarDomains/torch_utils/ops/grid_sample_gradfix.py:31-40: torch.nn.functional.grid_sample with
+    mode='bilinear', padding_mode='zeros', align_corners=False)."""
+    n, c, h, w = input.shape
+    ix = ((grid[..., 0] + 1) * w - 1) / 2
+    iy = ((grid[..., 1] + 1) * h - 1) / 2
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    out = 0
+    flat = input.reshape(n, c, h * w)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xi, yi = x0 + dx, y0 + dy
+            weight = (1 - (ix - xi).abs()) * (1 - (iy - yi).abs())              # [N, Ho, Wo]
+            inside = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1)
+            index = (yi.clamp(0, h - 1) * w + xi.clamp(0, w - 1)).long().reshape(n, 1, -1).expand(n, c, -1)
+            values = torch.gather(flat, 2, index).reshape(n, c, *ix.shape[1:])
+            out = out + values * (weight * inside.to(weight.dtype)).unsqueeze(1)
+    return out

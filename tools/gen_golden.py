@@ -272,6 +272,29 @@ def gen_misc_ops():
     b.save()
 
 
+def gen_grid_sample():
+    """grid_sample_gradfix of the reference with its custom op enabled: forward, first-order gradients of the
+    image and the grid, and the second-order gradient R1 takes through it (d/d image of |d out / d image|^2)."""
+    from torch_utils.ops import grid_sample_gradfix as ref_gs
+    g = torch.Generator().manual_seed(105)
+    b = Bundle('grid_sample')
+    ref_gs.enabled = True
+    for n, c, h, w, oh, ow, spread in ((2, 3, 8, 9, 7, 10, 1.2), (1, 4, 16, 16, 20, 12, 0.9), (3, 1, 5, 6, 5, 6, 1.6)):
+        x = rnd(g, n, c, h, w).requires_grad_(True)
+        grid = ((torch.rand(n, oh, ow, 2, generator=g) * 2 - 1) * spread).requires_grad_(True)
+        y = ref_gs.grid_sample(x, grid)
+        dy = rnd(g, *y.shape)
+        gx, ggrid = torch.autograd.grad((y * dy).sum(), [x, grid], create_graph=True)
+        v = rnd(g, *x.shape)
+        # second order: how the image gradient reacts to the incoming gradient (linear map: sampler applied to v)
+        dy2 = dy.clone().requires_grad_(True)
+        gx2, = torch.autograd.grad((ref_gs.grid_sample(x, grid.detach()) * dy2).sum(), x, create_graph=True)
+        g_dy, = torch.autograd.grad((gx2 * v).sum(), dy2)
+        b.add(dict(op='grid_sample', shape=[n, c, h, w], out=[oh, ow]), x=x, grid=grid, y=y, dy=dy, gx=gx, ggrid=ggrid, v=v, g_dy=g_dy)
+    ref_gs.enabled = False
+    b.save()
+
+
 # ----------------------------------------------------------------------------
 # Layers and networks.
 
@@ -515,7 +538,7 @@ def gen_full_size():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv2d_resample', 'modulated_conv2d', 'misc_ops', 'layers',
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv2d_resample', 'modulated_conv2d', 'misc_ops', 'grid_sample', 'layers',
                              'networks', 'loss', 'full_size']
     for name in which:
         globals()['gen_' + name]()
