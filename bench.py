@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--ada', action='store_true',
+                    help='adaptive discriminator augmentation (bgc pipe, target 0.6) in front of every D call; the '
+                         'headline figure is quoted without it')
     ap.add_argument('--graphs', action='store_true',
                     help='record the forward/backward of every phase into a HIP graph at the first step and replay it '
                          'afterwards (same speed on one GPU, where the step is GPU-bound; spares the host)')
@@ -55,7 +58,12 @@ def make_trainer(args, rank, world):
     opts = training_loop.setup_training_options(cfg=cfg, resolution=res, batch_size=batch_gpu * world, num_gpus=world,
                                                 batch_gpu=batch_gpu, glrate=0.02 if par != 'FULL' else None,
                                                 **getattr(training_loop, par))
-    return training_loop.Trainer(rank=rank, random_seed=0, use_graphs=bool(getattr(args, 'graphs', False)), **opts), desc, res, batch_gpu
+    extra = {}
+    if getattr(args, 'ada', False):
+        extra = dict(augment_pipe=training_loop.make_augment_pipe('bgc', 0.3, torch.device('cuda', torch.cuda.current_device())),
+                     ada_target=0.6)
+    return (training_loop.Trainer(rank=rank, random_seed=0, use_graphs=bool(getattr(args, 'graphs', False)), **extra, **opts),
+            desc + (' + ADA (bgc)' if extra else ''), res, batch_gpu)
 
 
 def measured_traffic(label):

@@ -244,12 +244,40 @@ class Phase:
         self.name, self.module, self.opt, self.interval = name, module, opt, interval
 
 
+# Augmentation presets of the reference's `--augpipe` flag (train.py:357-382).
+_BLIT = dict(xflip=1, rotate90=1, xint=1)
+_GEOM = dict(scale=1, rotate=1, aniso=1, xfrac=1)
+_COLOR = dict(brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1)
+AUGPIPE_SPECS = {
+    'blit': dict(_BLIT), 'geom': dict(_GEOM), 'color': dict(_COLOR), 'filter': dict(imgfilter=1), 'noise': dict(noise=1),
+    'cutout': dict(cutout=1), 'bg': dict(**_BLIT, **_GEOM), 'bgc': dict(**_BLIT, **_GEOM, **_COLOR),
+    'bgcf': dict(**_BLIT, **_GEOM, **_COLOR, imgfilter=1), 'bgcfn': dict(**_BLIT, **_GEOM, **_COLOR, imgfilter=1, noise=1),
+    'bgcfnc': dict(**_BLIT, **_GEOM, **_COLOR, imgfilter=1, noise=1, cutout=1),
+}
+
+
+def make_augment_pipe(augpipe='bgc', augment_p=0.0, device=None):
+    """The frozen AugmentPipe of a preset with its strength set (reference: training_loop.py:259-266)."""
+    from . import augment
+    pipe = augment.AugmentPipe(**AUGPIPE_SPECS[augpipe]).train().requires_grad_(False)
+    if device is not None:
+        pipe = pipe.to(device)
+    pipe.p.copy_(torch.as_tensor(float(augment_p)))
+    return pipe
+
+
 class Trainer:
-    """State and one-iteration step of the training loop, for one rank."""
+    """State and one-iteration step of the training loop, for one rank.
+
+    `augment_pipe` (an AugmentPipe) is applied in front of every discriminator call; with `ada_target` its strength
+    follows the reference's heuristic (training_loop.py:529-535): every `ada_interval` iterations the mean sign of
+    the discriminator's logits on real images is compared with the target and `p` moves by
+    batch_size * ada_interval / (ada_kimg * 1000) towards it (never below 0)."""
 
     def __init__(self, G_kwargs, D_kwargs, G_opt_kwargs, D_opt_kwargs, loss_kwargs=None, batch_size=32, batch_gpu=32,
                  num_gpus=1, rank=0, ema_kimg=10, ema_rampup=None, G_reg_interval=4, D_reg_interval=16,
-                 requires_grad_parts=None, device=None, random_seed=0, augment_pipe=None, resume=None, use_graphs=False):
+                 requires_grad_parts=None, device=None, random_seed=0, augment_pipe=None, resume=None, use_graphs=False,
+                 ada_target=None, ada_interval=4, ada_kimg=500):
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.rank, self.num_gpus = rank, num_gpus
         self.batch_size, self.batch_gpu = batch_size, batch_gpu
@@ -278,6 +306,15 @@ class Trainer:
                                               **(loss_kwargs or {}))
         self.requires_grad_parts = requires_grad_parts or {k: ['all'] for k in
                                                            ('Gboth', 'Gmain', 'Greg', 'Dboth', 'Dmain', 'Dreg')}
+        self.augment_pipe = augment_pipe
+        self.ada_target, self.ada_interval, self.ada_kimg = ada_target, ada_interval, ada_kimg
+        self.ada_stats = None
+        if augment_pipe is not None:
+            from ..torch_utils.ops import grid_sample_gradfix
+            grid_sample_gradfix.enabled = True     # R1 differentiates twice through the resampling (training_loop.py:210)
+            if ada_target is not None:
+                training_stats.enable(True)
+                self.ada_stats = training_stats.Collector(regex='Loss/signs/real')
         self.reducer = GradReducer(num_gpus)
         self.reducer.attach(list(self.G.parameters()) + list(self.D.parameters()))
         self.loss.grad_sync = None if use_graphs else self.reducer   # (a recorded phase exchanges after its replay)
@@ -389,6 +426,12 @@ class Trainer:
                 torch._foreach_copy_(list(self.G_ema.buffers()), list(self.G.buffers()))
         self.cur_nimg += self.batch_size
         self.batch_idx += 1
+        if self.ada_stats is not None and self.batch_idx % self.ada_interval == 0:
+            self.ada_stats.update()     # (all-reduces the sign statistics across ranks)
+            sign_real = self.ada_stats['Loss/signs/real']
+            if sign_real == sign_real:   # not NaN: at least one real batch was seen since the last update
+                adjust = np.sign(sign_real - self.ada_target) * (self.batch_size * self.ada_interval) / (self.ada_kimg * 1000)
+                self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp_min(0))
 
 
 def training_loop(total_kimg=1, kimg_per_tick=4, data_iterator=None, progress_fn=None, rank=0, verbose=True,

@@ -295,6 +295,46 @@ def gen_grid_sample():
     b.save()
 
 
+AUGMENT_SPECS = {
+    'blit': dict(xflip=1, rotate90=1, xint=1),
+    'geom': dict(scale=1, rotate=1, aniso=1, xfrac=1),
+    'color': dict(brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1),
+    'bgc': dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1,
+                saturation=1),
+    'filter_cutout': dict(imgfilter=1, cutout=1),
+    'bands': dict(imgfilter=1, imgfilter_bands=[1, 0, 1, 0.5], imgfilter_std=0.7),
+}
+
+
+def gen_augment():
+    """The reference's AugmentPipe with every random draw replaced by a percentile (its own `debug_percentile`
+    switch): outputs, image gradients and - for the geometric part - the gradient of an R1-style penalty."""
+    from training import augment as ref_augment
+    from torch_utils.ops import grid_sample_gradfix as ref_gs
+    ref_gs.enabled = True
+    g = torch.Generator().manual_seed(106)
+    b = Bundle('augment')
+    for name, spec in AUGMENT_SPECS.items():
+        pipe = ref_augment.AugmentPipe(**spec)
+        for (n, c, h, w) in ((2, 3, 32, 32), (2, 3, 24, 40), (2, 1, 32, 32)):
+            if c == 1 and name not in ('color', 'blit'):
+                continue
+            for q in (0.2, 0.45, 0.8):
+                x = (rnd(g, n, c, h, w) * 0.5).requires_grad_(True)
+                y = pipe(x, debug_percentile=q)
+                dy = rnd(g, *y.shape)
+                gx, = torch.autograd.grad((y * dy).sum(), x, create_graph=True)
+                extra = {}
+                if name in ('geom', 'bgc') and (h, w) == (32, 32):
+                    gy, = torch.autograd.grad(pipe(x, debug_percentile=q).square().sum(), x, create_graph=True)
+                    r1, = torch.autograd.grad(gy.square().sum(), x)
+                    extra = dict(r1=r1)
+                b.add(dict(spec=name, kwargs=spec, q=q, shape=[n, c, h, w]), x=x, y=y, dy=dy, gx=gx, **extra)
+    b.add(dict(spec='buffers'), Hz_geom=pipe.Hz_geom, Hz_fbank=pipe.Hz_fbank)
+    ref_gs.enabled = False
+    b.save()
+
+
 # ----------------------------------------------------------------------------
 # Layers and networks.
 
@@ -538,7 +578,7 @@ def gen_full_size():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv2d_resample', 'modulated_conv2d', 'misc_ops', 'grid_sample', 'layers',
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv2d_resample', 'modulated_conv2d', 'misc_ops', 'grid_sample', 'augment', 'layers',
                              'networks', 'loss', 'full_size']
     for name in which:
         globals()['gen_' + name]()
