@@ -340,6 +340,41 @@ class Trainer:
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
 
+    # -- snapshots ---------------------------------------------------------------
+    def snapshot(self):
+        """Everything a run needs to continue, as plain tensors and numbers: the three networks (the reference's
+        snapshot, training_loop.py:586-601, holds these) and what the reference loses on resume - optimizer
+        moments and step counts, the path-length average, the augmentation strength, the image counter."""
+        opts = {}
+        for phase in self.phases:
+            opts.setdefault(phase.name[0], phase.opt.state_dict())       # main / reg phases share one optimizer
+        state = dict(G=self.G.state_dict(), D=self.D.state_dict(), G_ema=self.G_ema.state_dict(), opt=opts,
+                     pl_mean=self.loss.pl_mean.detach().clone(), cur_nimg=self.cur_nimg, batch_idx=self.batch_idx)
+        if self.augment_pipe is not None:
+            state['augment_pipe'] = self.augment_pipe.state_dict()
+        return state
+
+    def load_snapshot(self, state):
+        self.G.load_state_dict(state['G'])
+        self.D.load_state_dict(state['D'])
+        self.G_ema.load_state_dict(state['G_ema'])
+        done = set()
+        for phase in self.phases:
+            if phase.name[0] in state.get('opt', {}) and phase.name[0] not in done:
+                phase.opt.load_state_dict(state['opt'][phase.name[0]])
+                done.add(phase.name[0])
+        self.loss.pl_mean.copy_(state['pl_mean'].to(self.device))
+        self.cur_nimg, self.batch_idx = int(state['cur_nimg']), int(state['batch_idx'])
+        if self.augment_pipe is not None and 'augment_pipe' in state:
+            self.augment_pipe.load_state_dict(state['augment_pipe'])
+
+    def save(self, path):
+        torch.save(self.snapshot(), path)
+
+    def load(self, path):
+        """Tensors, numbers and containers only: read with `weights_only=True` (nothing in the file is executed)."""
+        self.load_snapshot(torch.load(path, map_location=self.device, weights_only=True))
+
     # -- data ------------------------------------------------------------------
     def synthetic_batch(self, generator=None):
         """Uniform random uint8 images of this rank's share of the batch (and empty labels)."""

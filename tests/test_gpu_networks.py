@@ -289,3 +289,40 @@ def test_derived_tensor_cache_follows_parameter_writes():
         memo.enabled = True
     for a, w in zip(got, want):
         close(a, w, 1e-2, 'D gradient after an update')   # (a stale weight would be off by tens of percent)
+
+
+def test_trainer_snapshot_round_trip(tmp_path):
+    """A snapshot written after two iterations and loaded into a fresh trainer restores networks, optimizer moments,
+    counters and the path-length average; and the restored trainer keeps training."""
+    from ga_gan_amd.training import training_loop
+    opts = training_loop.setup_training_options(cfg='paper256', resolution=32, batch_size=4, **training_loop.AFFINE_PLUS)
+    for k in ('G_kwargs', 'D_kwargs'):
+        kw = opts[k].get('synthesis_kwargs', opts[k])
+        kw['channel_base'], kw['channel_max'] = 512, 32
+    kwargs = dict(random_seed=0, G_reg_interval=2, D_reg_interval=2, loss_kwargs=dict(style_mixing_prob=0), **{k: v for k, v in opts.items() if k != 'loss_kwargs'})
+    a = training_loop.Trainer(**kwargs)
+    a.loss.synthesis_kwargs = dict(noise_mode='const')
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    batches = [a.synthetic_batch(gen) for _ in range(3)]
+    zs = [torch.randn(len(a.phases) * 4, 512, device=DEV, generator=gen) for _ in range(3)]
+    for i in range(2):
+        a.step(*batches[i], gen_z=zs[i])
+    path = str(tmp_path / 'snapshot.pt')
+    a.save(path)
+    b = training_loop.Trainer(**kwargs)
+    b.loss.synthesis_kwargs = dict(noise_mode='const')
+    b.load(path)
+    assert (b.cur_nimg, b.batch_idx) == (a.cur_nimg, a.batch_idx) == (8, 2)
+    close(b.loss.pl_mean, a.loss.pl_mean, 1e-7, 'pl_mean')
+    for (n, p), q in zip(a.G.named_parameters(), b.G.parameters()):
+        assert torch.equal(p, q), n
+    for pa, pb in zip(a.phases, b.phases):      # optimizer moments and step counts, parameter by parameter
+        for p, q in zip(pa.module.parameters(), pb.module.parameters()):
+            sa, sb = pa.opt.state.get(p, {}), pb.opt.state.get(q, {})
+            assert sorted(sa) == sorted(sb), pa.name
+            for key in sa:
+                assert torch.equal(torch.as_tensor(sa[key]).cpu(), torch.as_tensor(sb[key]).cpu()), (pa.name, key)
+    a.step(*batches[2], gen_z=zs[2])
+    b.step(*batches[2], gen_z=zs[2])             # (the restored trainer keeps training)
+    assert (b.cur_nimg, b.batch_idx) == (12, 3)
+    assert all(bool(torch.isfinite(p).all()) for p in list(b.G.parameters()) + list(b.D.parameters()))
