@@ -439,11 +439,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
                 for (int pl = 0; pl < 3; pl++) b[pl] = *reinterpret_cast<const uint4*>(s_in + b_addr[j] + tap_off + pl * 64);
 #pragma unroll
                 for (int m = 0; m < M_TILES; m++) {
-#ifndef SG_ABL_NOMMA
                     mma_split(a[m], b, acc[m][j]);
-#else
-                    acc[m][j][0] += __builtin_bit_cast(float, a[m][0].x ^ b[0].x ^ a[m][1].y ^ b[1].y ^ a[m][2].z ^ b[2].z);
-#endif
                 }
             }
         }
@@ -504,24 +500,16 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             }
             while (c0 < c_end) {
                 __syncthreads();   // the previous stage's fragments have been read
-#ifdef SG_ABL_NOCOMMIT
-                if (c0 == c_begin && g0 == 0) {
-#endif
                 if (new_chunk) x_commit(c0);
                 w_commit(g0);
-#ifdef SG_ABL_NOCOMMIT
-                }
-#endif
                 __syncthreads();
                 int nc0 = c0, ng0 = g0 + kSplitTaps;
                 bool next_new = false;
                 if (ng0 >= taps) { ng0 = 0; nc0 = c0 + KCH; next_new = true; }
-#ifndef SG_ABL_NOLOAD
                 if (nc0 < c_end) {
                     w_load(nc0, ng0);
                     if (next_new) x_load(nc0);
                 }
-#endif
                 split_multiply(g0, min(kSplitTaps, taps - g0));
                 c0 = nc0; g0 = ng0; new_chunk = next_new;
             }

@@ -127,16 +127,10 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
         const int img0 = rest * t.imgs;
         const int a0 = ta * t.th, b0 = tb * t.tw;
         __syncthreads();
-#ifdef SG_ABL_NOSTAGE
-        if (tile == (int)blockIdx.x) {
-#endif
         if (x_vec) stage<true>(s_x, x, p.x_scale, p.n, p.cx, p.h, p.w_in, cx0, img0, t.imgs, a0 * p.step + p.dy0, b0 * p.step + p.dx0, t.lh, t.lw);
         else stage<false>(s_x, x, p.x_scale, p.n, p.cx, p.h, p.w_in, cx0, img0, t.imgs, a0 * p.step + p.dy0, b0 * p.step + p.dx0, t.lh, t.lw);
         if (g_vec) stage<true>(s_g, g, p.g_scale, p.n, p.cg, p.gh, p.gw, cg0, img0, t.imgs, a0, b0, t.th, t.tw);
         else stage<false>(s_g, g, p.g_scale, p.n, p.cg, p.gh, p.gw, cg0, img0, t.imgs, a0, b0, t.th, t.tw);
-#ifdef SG_ABL_NOSTAGE
-        }
-#endif
         __syncthreads();
 
         for (int ri = 0; ri < t.imgs; ri++) {
@@ -189,9 +183,6 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
                 for (int r = 0; r < 4; r++) {
                     const int cg = cg0 + (wave >> 1) * 32 + m * 16 + lgrp * 4 + r;
                     const int cx = cx0 + (wave & 1) * 32 + n * 16 + lrow;
-#ifdef SG_ABL_NOATOMIC
-                    if (acc[tp][m][n][r] == 12345.f)
-#endif
                     if (cg < p.cg && cx < p.cx) atomicAdd(dw + ((int64_t)tp * p.cg + cg) * p.cx + cx, acc[tp][m][n][r]);
                 }
 }
