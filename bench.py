@@ -24,7 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'float': 157.3}   # dense matrix-core peaks
+# dense matrix-core peaks.  float32 convolutions run on the bf16 instruction, six partial products per float product
+# (exact three-way split of both operands): their ceiling in float-equivalent flops is a sixth of the bf16 peak.
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'float': 2500.0 / 6}
 
 CONFIGS = {
     # name: (description, cfg preset, resolution, per-GPU batch, parameterisation)
