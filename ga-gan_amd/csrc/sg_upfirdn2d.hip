@@ -362,6 +362,16 @@ int launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
         if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return launch_tiled<T, 2, 2, 1, 1, 4, 4, 64, 16>(p, stream);
         if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return launch_tiled<T, 1, 1, 2, 2, 4, 4, 64, 8>(p, stream);
     }
+    // One-dimensional passes of a separable filter of up to 12 taps at a factor of two (the wavelet low-pass of the
+    // augmentation pipeline's geometric resampler, reference augment.py:352 and :370, and their adjoints).
+    if (rows_contiguous && sizeof(T) <= 4 && p.f_w <= 12 && p.f_h == 1 && p.up_y == 1 && p.down_y == 1) {
+        if (p.up_x == 2 && p.down_x == 1) return launch_tiled<T, 2, 1, 1, 1, 12, 1, 64, 16>(p, stream);
+        if (p.up_x == 1 && p.down_x == 2) return launch_tiled<T, 1, 1, 2, 1, 12, 1, 64, 16>(p, stream);
+    }
+    if (rows_contiguous && sizeof(T) <= 4 && p.f_h <= 12 && p.f_w == 1 && p.up_x == 1 && p.down_x == 1) {
+        if (p.up_y == 2 && p.down_y == 1) return launch_tiled<T, 1, 2, 1, 1, 1, 12, 64, 16>(p, stream);
+        if (p.up_y == 1 && p.down_y == 2) return launch_tiled<T, 1, 1, 1, 2, 1, 12, 64, 8>(p, stream);
+    }
     return launch_generic<T>(p, stream);
 }
 

@@ -16,6 +16,12 @@ The geometric ones compose into ONE inverse homogeneous transform per image, exe
 with negative padding and flipped filter).  The colour ones compose into one 4 x 4 matrix per image.
 `debug_percentile` replaces every random draw by that percentile of its distribution, which is how the
 parity fixtures are made deterministic.
+
+The per-image parameters (coins, angles, factors, the composed matrices, the reflect-padding margins that follow
+from them) are a few hundred numbers: they are drawn and composed on the host and uploaded once per call from
+pinned memory, so that the call never waits for the GPU (the reference composes them on the device and reads the
+margins back, augment.py:341-347, which drains the launch queue in front of every discriminator pass).  Only `p`
+lives on the device, as the reference's buffer does; its value is read back when the buffer changes.
 """
 import numpy as np
 import torch
@@ -113,11 +119,27 @@ class AugmentPipe(torch.nn.Module):
         self.register_buffer('Hz_geom', upfirdn2d.setup_filter(WAVELETS['sym6']))
         self.register_buffer('Hz_fbank', torch.as_tensor(_filter_bank(), dtype=torch.float32))
 
+        self._p_seen = None                             # (stamp of the buffer, its value on the host)
+
     # -- random draws -----------------------------------------------------------------
+    def strength(self):
+        """Value of the buffer `p` on the host; read back (one synchronisation) only after the buffer was written."""
+        stamp = (self.p.data_ptr(), self.p._version, self.p.device)
+        if self._p_seen is None or self._p_seen[0] != stamp:
+            self._p_seen = (stamp, float(self.p))
+        return self._p_seen[1]
+
     def _gated(self, value, multiplier, identity):
         """`value` where a per-image coin with probability multiplier * p comes up, else the identity parameter."""
         coin = torch.rand([value.shape[0]] + [1] * (value.ndim - 1), device=value.device)
-        return torch.where(coin < multiplier * self.p, value, torch.full_like(value, identity))
+        return torch.where(coin < multiplier * self.strength(), value, torch.full_like(value, identity))
+
+    @staticmethod
+    def _upload(t, device):
+        """Host tensor of parameters -> device, without waiting for the device."""
+        if device.type == 'cpu':
+            return t
+        return t.contiguous().pin_memory().to(device, non_blocking=True)
 
     @staticmethod
     def _normal_percentile(q):
@@ -127,9 +149,10 @@ class AugmentPipe(torch.nn.Module):
         assert isinstance(images, torch.Tensor) and images.ndim == 4
         n, channels, height, width = images.shape
         dev = images.device
-        q = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
-        rand = lambda *shape: torch.rand(shape, device=dev)
-        randn = lambda *shape: torch.randn(shape, device=dev)
+        host = torch.device('cpu')                  # where the per-image parameters are drawn and composed
+        q = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=host)
+        rand = lambda *shape: torch.rand(shape, device=host)
+        randn = lambda *shape: torch.randn(shape, device=host)
         fixed = lambda like, value: torch.full_like(like, value) if not isinstance(value, torch.Tensor) else value.expand_as(like).clone()
 
         # ---- geometric part: G maps output pixel coordinates to input pixel coordinates -----------------------
@@ -161,7 +184,7 @@ class AugmentPipe(torch.nn.Module):
             compose(_scale2(1 / s, 1 / s))
         # a rotation before and one after the anisotropic scaling; each with probability p_rot so that
         # P(at least one) = rotate * p
-        p_rot = 1 - torch.sqrt((1 - self.rotate * self.p).clamp(0, 1))
+        p_rot = 1 - np.sqrt(np.clip(1 - self.rotate * self.strength(), 0, 1))
         if self.rotate > 0:
             theta = (rand(n) * 2 - 1) * np.pi * self.rotate_max
             theta = torch.where(rand(n) < p_rot, theta, torch.zeros_like(theta))
@@ -196,8 +219,8 @@ class AugmentPipe(torch.nn.Module):
             C = m if C is None else m @ C
 
         luma = np.asarray([1, 1, 1, 0]) / np.sqrt(3)
-        outer = torch.as_tensor(np.outer(luma, luma), dtype=torch.float32, device=dev)
-        eye4 = torch.eye(4, device=dev)
+        outer = torch.as_tensor(np.outer(luma, luma), dtype=torch.float32, device=host)
+        eye4 = torch.eye(4, device=host)
         if self.brightness > 0:
             b = self._gated(randn(n) * self.brightness_std, self.brightness, 0)
             if q is not None:
@@ -224,7 +247,7 @@ class AugmentPipe(torch.nn.Module):
                 s = fixed(s, torch.exp2(self._normal_percentile(q) * self.saturation_std))
             colour(outer + (eye4 - outer) * s)
         if C is not None:
-            C = C.expand(n, 4, 4) if C.ndim == 2 else C
+            C = self._upload(C.expand(n, 4, 4) if C.ndim == 2 else C, dev)
             flat = images.reshape(n, channels, height * width)
             if channels == 3:
                 flat = C[:, :3, :3] @ flat + C[:, :3, 3:]
@@ -239,17 +262,17 @@ class AugmentPipe(torch.nn.Module):
         if self.imgfilter > 0:
             bands = self.Hz_fbank.shape[0]
             assert len(self.imgfilter_bands) == bands
-            expected_power = torch.as_tensor(np.array([10, 1, 1, 1]) / 13, dtype=torch.float32, device=dev)   # 1/f spectrum
-            gain = torch.ones([n, bands], device=dev)
+            expected_power = torch.as_tensor(np.array([10, 1, 1, 1]) / 13, dtype=torch.float32, device=host)   # 1/f spectrum
+            gain = torch.ones([n, bands], device=host)
             for i, strength in enumerate(self.imgfilter_bands):
                 t_i = self._gated(torch.exp2(randn(n) * self.imgfilter_std), self.imgfilter * strength, 1)
                 if q is not None:
                     t_i = fixed(t_i, torch.exp2(self._normal_percentile(q) * self.imgfilter_std)) if strength > 0 else torch.ones_like(t_i)
-                t = torch.ones([n, bands], device=dev)
+                t = torch.ones([n, bands], device=host)
                 t[:, i] = t_i
                 t = t / (expected_power * t.square()).sum(dim=-1, keepdim=True).sqrt()      # keep the expected power
                 gain = gain * t
-            taps = (gain @ self.Hz_fbank).unsqueeze(1).repeat([1, channels, 1]).reshape(n * channels, 1, -1)
+            taps = (self._upload(gain, dev) @ self.Hz_fbank).unsqueeze(1).repeat([1, channels, 1]).reshape(n * channels, 1, -1)
             pad = self.Hz_fbank.shape[1] // 2
             images = images.reshape(1, n * channels, height, width)
             images = torch.nn.functional.pad(images, [pad, pad, pad, pad], mode='reflect')
@@ -262,25 +285,26 @@ class AugmentPipe(torch.nn.Module):
             sigma = self._gated(randn(n, 1, 1, 1).abs() * self.noise_std, self.noise, 0)
             if q is not None:
                 sigma = fixed(sigma, torch.erfinv(q) * self.noise_std)
-            images = images + randn(n, channels, height, width) * sigma
+            images = images + torch.randn([n, channels, height, width], device=dev) * self._upload(sigma, dev)
         if self.cutout > 0:
-            size = self._gated(torch.full([n, 2, 1, 1, 1], self.cutout_size, device=dev), self.cutout, 0)
+            size = self._gated(torch.full([n, 2, 1, 1, 1], self.cutout_size, device=host), self.cutout, 0)
             center = rand(n, 2, 1, 1, 1)
             if q is not None:
                 size = torch.full_like(size, self.cutout_size)
                 center = fixed(center, q)
             xs = (torch.arange(width, device=dev).reshape(1, 1, 1, -1) + 0.5) / width
             ys = (torch.arange(height, device=dev).reshape(1, 1, -1, 1) + 0.5) / height
+            size, center = self._upload(size, dev), self._upload(center, dev)
             keep = ((xs - center[:, 0]).abs() >= size[:, 0] / 2) | ((ys - center[:, 1]).abs() >= size[:, 1] / 2)
             images = images * keep.to(torch.float32)
         return images
 
     # -- geometric execution ---------------------------------------------------------------
     def _resample(self, images, G):
-        """images sampled through the inverse transform G [N, 3, 3] (output pixel -> input pixel, origin at the
-        image centre), band-limited by working on a 2x finer grid (reference: augment.py:338-370)."""
+        """images sampled through the inverse transform G [N, 3, 3] on the host (output pixel -> input pixel, origin
+        at the image centre), band-limited by working on a 2x finer grid (reference: augment.py:338-370)."""
         n, channels, height, width = images.shape
-        dev = images.device
+        dev = G.device
         G = G.expand(n, 3, 3) if G.ndim == 2 else G
         taps_pad = self.Hz_geom.shape[0] // 4
         # how far the transformed image corners reach beyond the frame decides the reflect padding
@@ -300,6 +324,6 @@ class AugmentPipe(torch.nn.Module):
 
         shape = [n, channels, (height + taps_pad * 2) * 2, (width + taps_pad * 2) * 2]
         G = _scale2(2 / images.shape[3], 2 / images.shape[2], device=dev) @ G @ _scale2(shape[3] / 2, shape[2] / 2, device=dev)
-        grid = torch.nn.functional.affine_grid(theta=G[:, :2, :], size=shape, align_corners=False)
+        grid = torch.nn.functional.affine_grid(theta=self._upload(G[:, :2, :], images.device), size=shape, align_corners=False)
         images = grid_sample_gradfix.grid_sample(images, grid)
         return upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-taps_pad * 2, flip_filter=True)

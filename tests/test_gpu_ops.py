@@ -105,7 +105,41 @@ def test_upfirdn2d_hot_shapes_vs_oracle(name, shape, up, down, pad, gain, dtype)
     # adjoint identity <A x, v> == <x, A^T v> (backward runs the kernel with up/down swapped)
     v = torch.randn(y.shape, generator=g).to(dtype).to(DEV)
     gx, = torch.autograd.grad((y.float() * v.float()).sum(), xd)
-    lhs = float((y.double() * v.double()).sum())
+    lhs = float((y.detach().double() * v.double()).sum())
+    rhs = float((xd.detach().double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= (5e-2 if dtype != torch.float32 else 1e-4) * max(abs(lhs), 1.0), (lhs, rhs)
+
+
+SEPARABLE = [  # (name, x shape, taps, up, down, padding, flip): one-dimensional passes of the resampler's low-pass
+    ('wavelet_up', [3, 3, 141, 150], 12, 2, 1, [6, 5, 6, 5], False),
+    ('wavelet_down', [3, 3, 283, 301], 12, 1, 2, [-6, -6, -6, -6], True),
+    ('wavelet_down_padded', [2, 3, 130, 77], 12, 1, 2, [5, 6, 5, 6], False),
+    ('seven_taps_up', [2, 5, 67, 45], 7, 2, 1, [4, 3, 3, 4], True),
+    ('nine_taps_down', [2, 5, 67, 45], 9, 1, 2, [3, 4, 4, 3], False),
+]
+
+
+@pytest.mark.parametrize('name,shape,taps,up,down,pad,flip', SEPARABLE, ids=[h[0] for h in SEPARABLE])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_upfirdn2d_separable_vs_oracle(name, shape, taps, up, down, pad, flip, dtype):
+    upfirdn2d = ops()[0]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g).to(dtype)
+    f = torch.randn([taps], generator=g)
+    f = f / f.sum()
+    gain = float(up * up)
+    want = resample.upfirdn2d(x.double(), f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+    xd = x.to(DEV).requires_grad_(True)
+    y = upfirdn2d.upfirdn2d(xd, f.to(DEV), up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+    assert y.shape == want.shape
+    close(y, want, 4 * ULP[dtype], name)
+    # channels-last input takes the kernel that walks the taps in global memory
+    y2 = upfirdn2d.upfirdn2d(xd.detach().contiguous(memory_format=torch.channels_last), f.to(DEV), up=up, down=down,
+                             padding=pad, flip_filter=flip, gain=gain)
+    close(y2, y, 4 * ULP[dtype], name + ' tiled-vs-generic')
+    v = torch.randn(y.shape, generator=g).to(dtype).to(DEV)
+    gx, = torch.autograd.grad((y.float() * v.float()).sum(), xd)
+    lhs = float((y.detach().double() * v.double()).sum())
     rhs = float((xd.detach().double() * gx.double()).sum())
     assert abs(lhs - rhs) <= (5e-2 if dtype != torch.float32 else 1e-4) * max(abs(lhs), 1.0), (lhs, rhs)
 
