@@ -46,3 +46,52 @@ def copy_params_and_buffers(src_module, dst_module, require_all=False):
 
 def nan_to_num_(t, nan=0.0, posinf=1e5, neginf=-1e5):
     return torch.nan_to_num(t, nan=nan, posinf=posinf, neginf=neginf, out=t)
+
+
+class InfiniteSampler:
+    """Endless stream of dataset indices for one rank (same arguments and the same sequence as the reference's
+    sampler, torch_utils/misc.py:117-148): a seeded permutation is walked cyclically; after position i has been
+    visited, its entry trades places with one at most `window_size * len(dataset)` positions earlier, so the
+    order keeps drifting; rank r of num_replicas takes the visits whose running number is r modulo num_replicas.
+    Usable as the `sampler` of a torch DataLoader and as a plain iterator (`take(n)`)."""
+
+    def __init__(self, dataset, rank=0, num_replicas=1, shuffle=True, seed=0, window_size=0.5):
+        if len(dataset) <= 0:
+            raise ValueError('the dataset is empty')
+        if not (num_replicas > 0 and 0 <= rank < num_replicas):
+            raise ValueError(f'rank {rank} is not one of {num_replicas} replicas')
+        if not 0 <= window_size <= 1:
+            raise ValueError('window_size must lie in [0, 1]')
+        self.dataset = dataset
+        self.rank = rank
+        self.num_replicas = num_replicas
+        self.shuffle = shuffle
+        self.seed = seed
+        self.window_size = window_size
+        self._running = None
+
+    def __iter__(self):
+        import numpy as np
+        size = len(self.dataset)
+        order = np.arange(size)
+        draw, window = None, 0
+        if self.shuffle:
+            draw = np.random.RandomState(self.seed)
+            draw.shuffle(order)
+            window = int(np.rint(size * self.window_size))
+        visit = 0
+        while True:
+            here = visit % size
+            if visit % self.num_replicas == self.rank:
+                yield order[here]
+            if window >= 2:
+                there = (here - draw.randint(window)) % size
+                order[here], order[there] = order[there], order[here]
+            visit += 1
+
+    def take(self, n):
+        """The next n indices of one continuing pass (host int64 array)."""
+        import numpy as np
+        if self._running is None:
+            self._running = iter(self)
+        return np.fromiter((next(self._running) for _ in range(n)), dtype=np.int64, count=n)

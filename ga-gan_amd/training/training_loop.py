@@ -21,6 +21,7 @@ import time
 import numpy as np
 import torch
 
+from .. import images_plugin
 from .. import optim_plugin
 from ..torch_utils import misc
 from ..torch_utils import training_stats
@@ -419,7 +420,9 @@ class Trainer:
         n_rank = self.batch_size // self.num_gpus
         with torch.autograd.profiler.record_function('data_fetch'):
             real = real_img.to(self.device)
-            if not real.is_floating_point():
+            if real.dtype == torch.uint8 and real.ndim == 4:
+                real = images_plugin.images_to_float(real)
+            elif not real.is_floating_point():
                 real = real.to(torch.float32) / 127.5 - 1
             phase_real_img = real.split(self.batch_gpu)
             phase_real_c = real_c.to(self.device).split(self.batch_gpu)

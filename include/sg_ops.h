@@ -314,6 +314,28 @@ typedef struct sg_lerp_params {
 
 int sg_lerp_multi(const sg_lerp_params* p, sg_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * A batch of training images from a uint8 image set resident in device memory:
+ *   out[b, c, y, x] = (float)images[index[b], c, y, flip[b] ? w - 1 - x : x] / 127.5f - 1.0f
+ * (float32 arithmetic with a correctly rounded division, then rounded once to `dtype`).  It replaces the host-side
+ * gather of the reference's loader (`Dataset.__getitem__` with its left-right mirror, training/dataset.py:85-93,
+ * batched by the DataLoader of training/training_loop.py:221-223) plus the conversion on the device
+ * (`phase_real_img.to(device).to(torch.float32) / 127.5 - 1`, training/training_loop.py:441) by one pass that reads
+ * one byte and writes one element per pixel.  `index` and `flip` are device arrays of n entries; either may be NULL
+ * (identity order / no mirror).  An index outside [0, count) yields NaN for that sample instead of a wild read.
+ */
+typedef struct sg_images_params {
+    const uint8_t* images;  /* [count, c, h, w] dense */
+    const int64_t* index;   /* device [n] or NULL */
+    const uint8_t* flip;    /* device [n] or NULL */
+    void* out;              /* [n, c, h, w] dense, element type dtype (SG_F32, SG_F16 or SG_BF16) */
+    int32_t dtype;
+    int32_t n, c, h, w;
+    int64_t count;
+} sg_images_params;
+
+int sg_images_to_float(const sg_images_params* p, sg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,6 +335,61 @@ def gen_augment():
     b.save()
 
 
+def gen_data_path():
+    """The reference's ImageFolderDataset and InfiniteSampler on synthetic PNG folders (written by oracle/data.py, which
+    the tests call again to rebuild the same files), and its uint8 -> [-1, 1] conversion of every byte value."""
+    import tempfile
+    from training import dataset as ref_dataset
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import data as odata
+    b = Bundle('data_path')
+    with tempfile.TemporaryDirectory() as tmp:
+        folders = [  # (name, count, channels, resolution, seed, labels, zip?)
+            ('rgb_dir', 11, 3, 16, 21, 'int', False),
+            ('rgb_zip', 7, 3, 8, 22, 'float', True),
+            ('gray_dir', 5, 1, 16, 23, None, False),
+        ]
+        for name, count, channels, res, seed, kind, as_zip in folders:
+            images = odata.synthetic_images(count, channels, res, seed)
+            labels = None
+            if kind == 'int':
+                labels = [int(v) for v in np.random.RandomState(seed + 100).randint(0, 4, size=count)]
+            elif kind == 'float':
+                labels = np.random.RandomState(seed + 100).randn(count, 3).astype(np.float32).round(3)
+            path = os.path.join(tmp, name + ('.zip' if as_zip else ''))
+            if not as_zip:
+                os.makedirs(path)
+            odata.write_image_folder(path, images, labels, as_zip=as_zip)
+            for kwargs in (dict(), dict(use_labels=True), dict(max_size=4, random_seed=5, xflip=True, use_labels=True),
+                           dict(xflip=True), dict(max_size=3, random_seed=1)):
+                ds = ref_dataset.ImageFolderDataset(path=path, resolution=res, **kwargs)
+                items = [ds[i] for i in range(len(ds))]
+                b.add(dict(op='dataset', folder=name, count=count, channels=channels, resolution=res, seed=seed, labels=kind,
+                           zip=as_zip, kwargs=kwargs, name=ds.name, image_shape=ds.image_shape, label_shape=ds.label_shape,
+                           label_dim=ds.label_dim, has_labels=bool(ds.has_labels), has_onehot_labels=bool(ds.has_onehot_labels),
+                           length=len(ds), details=[[int(ds.get_details(i).raw_idx), bool(ds.get_details(i).xflip)] for i in range(len(ds))]),
+                      images=np.stack([im for im, _ in items]), item_labels=np.stack([lb for _, lb in items]),
+                      get_label=np.stack([ds.get_label(i) for i in range(len(ds))]))
+                ds.close()
+    for size, replicas, shuffle, seed, window in ((10, 1, True, 0, 0.5), (10, 2, True, 3, 0.5), (37, 4, True, 7, 0.5), (10, 1, False, 0, 0.5),
+                                                  (10, 3, True, 1, 0.0), (6, 2, True, 2, 1.0), (1, 1, True, 0, 0.5), (3, 1, True, 9, 0.5)):
+        class _Sized:
+            def __len__(self):
+                return size
+        per_rank = []
+        for rank in range(replicas):
+            # (the constructor hands the dataset to torch's Sampler base class, which no longer takes one:
+            # the attributes it would set are set here, the iteration is the reference's)
+            sampler = ref_misc.InfiniteSampler.__new__(ref_misc.InfiniteSampler)
+            sampler.__dict__.update(dataset=_Sized(), rank=rank, num_replicas=replicas, shuffle=shuffle, seed=seed, window_size=window)
+            it = iter(sampler)
+            per_rank.append([int(next(it)) for _ in range(64)])
+        b.add(dict(op='sampler', size=size, num_replicas=replicas, shuffle=shuffle, seed=seed, window_size=window), order=np.asarray(per_rank))
+    every = torch.arange(256, dtype=torch.uint8)
+    b.add(dict(op='to_float'), u8=every, f32=every.to(torch.float32) / 127.5 - 1)
+    b.save()
+
+
 # ----------------------------------------------------------------------------
 # Layers and networks.
 
@@ -578,7 +633,7 @@ def gen_full_size():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv2d_resample', 'modulated_conv2d', 'misc_ops', 'grid_sample', 'augment', 'layers',
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv2d_resample', 'modulated_conv2d', 'misc_ops', 'grid_sample', 'augment', 'data_path', 'layers',
                              'networks', 'loss', 'full_size']
     for name in which:
         globals()['gen_' + name]()
