@@ -346,12 +346,35 @@ class _ScaledCast(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.to(ctx.src_dtype)
-        return (g * ctx.gain if ctx.gain != 1 else g), None, None, None, None
+        if torch.is_grad_enabled():      # a higher-order graph is wanted: differentiable composition
+            g = g.to(ctx.src_dtype)
+            return (g * ctx.gain if ctx.gain != 1 else g), None, None, None, None
+        return _scaled_cast(g, ctx.gain, ctx.src_dtype), None, None, None, None
+
+
+_GAINS = {}
+
+
+def _gain_vector(gain, device):
+    """float32 [1] tensor holding `gain` (a one-element vector, unlike a scalar, takes part in type promotion)."""
+    key = (float(gain), device)
+    vec = _GAINS.get(key)
+    if vec is None:
+        vec = torch.full([1], float(gain), dtype=torch.float32, device=device)
+        if not (vec.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _GAINS[key] = vec
+    return vec
 
 
 def _scaled_cast(tensor, gain, dtype):
-    return (tensor * gain).to(dtype) if gain != 1 else tensor.to(dtype)
+    """(tensor * gain).to(dtype) without a graph, as one kernel: the product is formed in float32 and rounded once."""
+    if gain == 1 or tensor.dtype == dtype:
+        return tensor.to(dtype) if gain == 1 else tensor * gain
+    if dtype == torch.float32:           # 16-bit -> float32: promotion against the float32 vector widens first
+        return tensor * _gain_vector(gain, tensor.device)
+    if tensor.dtype == torch.float32:    # float32 -> 16-bit: product in float32, written in the narrow type
+        return torch.mul(tensor, gain, out=torch.empty_like(tensor, dtype=dtype))
+    return (tensor * gain).to(dtype)
 
 
 def _prepared(owner, tensor, gain, dtype, key):
