@@ -12,6 +12,11 @@ from ..torch_utils import training_stats
 from ..torch_utils.ops import conv2d_gradfix
 
 
+def _interleave(a, b, groups):
+    """[n, ...] x 2 -> [2n, ...]: rows split into `groups` runs; run g of a, then run g of b, for g = 0, 1, ..."""
+    return torch.cat([a.unflatten(0, (groups, -1)), b.unflatten(0, (groups, -1))], dim=1).flatten(0, 1)
+
+
 class Loss:
     def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain):
         raise NotImplementedError()
@@ -34,10 +39,31 @@ class StyleGAN2Loss(Loss):
         self.pl_mean = torch.zeros([], device=device)
         self.synthesis_kwargs = {}      # e.g. dict(noise_mode='const') for deterministic runs
         self.grad_sync = None           # object with arm(): told when the next backward call's gradients are final
+        self.merge_D_passes = True      # Dmain: generated and real half in one discriminator pass (same result)
+        self._mbstd_sizes = None
 
     def _arm(self, sync):
         if sync and self.grad_sync is not None:
             self.grad_sync.arm()
+
+    def _merged_groups(self, n_gen, n_real):
+        """The discriminator's minibatch-std group size when the generated and the real half of Dmain can share one
+        discriminator pass (it is the number of runs `_interleave` cuts each half into), else None.  The reference runs two passes (loss.py:118-125 and :129-151); samples only
+        meet in the minibatch standard deviation, whose groups are the samples with equal index modulo
+        batch / group_size (networks.py:1291-1293), so one pass over [gen rows of group-row 0, real rows of group-row 0,
+        gen rows of group-row 1, ...] forms exactly the groups of the two separate passes and every logit is the same."""
+        if not self.merge_D_passes or n_gen != n_real or n_gen == 0:
+            return None
+        if self._mbstd_sizes is None:
+            known = type(self.D).__module__.endswith('training.networks') and type(self.D).__name__ == 'Discriminator'
+            layers = [m for m in self.D.modules() if type(m).__name__ == 'MinibatchStdLayer']
+            self._mbstd_sizes = [m.group_size for m in layers] if known else [None]
+        group = None
+        for size in self._mbstd_sizes:
+            if size is None or size > n_gen or n_gen % size != 0 or (group is not None and size != group):
+                return None          # whole-batch groups (or a discriminator this loss does not know): two passes
+            group = size
+        return group if group is not None else 1
 
     def run_G(self, z, c, sync, set_w_requires_grad=False):
         ws = self.G_mapping(z, c)
@@ -99,6 +125,31 @@ class StyleGAN2Loss(Loss):
             with torch.autograd.profiler.record_function('Gpl_backward'):
                 self._arm(sync)
                 (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
+
+        # Dmain, both halves in one discriminator pass where that is the same computation.
+        groups = self._merged_groups(gen_z.shape[0], real_img.shape[0]) if do_Dmain and not do_Dr1 else None
+        if groups is not None:
+            with torch.autograd.profiler.record_function('Dmain_forward'):
+                gen_img, _ = self.run_G(gen_z, gen_c, sync=False)
+                if self.augment_pipe is not None:
+                    gen_img, real_aug = self.augment_pipe(gen_img), self.augment_pipe(real_img.detach())
+                else:
+                    real_aug = real_img.detach()
+                logits = self.D(_interleave(gen_img, real_aug, groups), _interleave(gen_c, real_c, groups))
+                per_group = logits.unflatten(0, (groups, -1))
+                half = per_group.shape[1] // 2
+                gen_logits, real_logits = per_group[:, :half].flatten(0, 1), per_group[:, half:].flatten(0, 1)
+                training_stats.report('Loss/scores/fake', gen_logits)
+                training_stats.report('Loss/signs/fake', gen_logits.sign())
+                training_stats.report('Loss/scores/real', real_logits)
+                training_stats.report('Loss/signs/real', real_logits.sign())
+                loss_Dgen = torch.nn.functional.softplus(gen_logits)
+                loss_Dreal = torch.nn.functional.softplus(-real_logits)
+                training_stats.report('Loss/D/loss', loss_Dgen + loss_Dreal)
+            with torch.autograd.profiler.record_function('Dmain_backward'):
+                self._arm(sync)
+                (loss_Dgen.mean() + loss_Dreal.mean()).mul(gain).backward()
+            return
 
         # Dmain: minimise logits of generated images.
         loss_Dgen = 0

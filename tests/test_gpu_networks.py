@@ -162,6 +162,39 @@ def test_loss_phases(case):
         module.requires_grad_(False)
 
 
+@pytest.mark.parametrize('batch,group', [(8, 4), (8, 8), (12, 4), (4, 8), (6, None)])
+def test_dmain_single_pass_equals_two_passes(batch, group):
+    """Dmain with both halves in one discriminator pass (rows interleaved so that the minibatch-std groups are the
+    ones of two separate passes) against the reference's two passes: logits statistics and every gradient."""
+    from ga_gan_amd.training import loss as loss_module
+    from ga_gan_amd.torch_utils import training_stats
+    case = golden_io.load('loss')[0]
+    m = dict(case.meta, c_dim=0)
+    G, D = build_G(m), build_D(dict(m, mbstd_group_size=group))
+    G.load_state_dict(case.group('G.'), strict=True)
+    D.load_state_dict(case.group('D.'), strict=True)
+    G.to(DEV).train().requires_grad_(False)
+    D.to(DEV).train().requires_grad_(True)
+    loss = loss_module.StyleGAN2Loss(device=torch.device(DEV), G_mapping=G.mapping, G_synthesis=G.synthesis, D=D, style_mixing_prob=0)
+    loss.synthesis_kwargs = dict(noise_mode='const')
+    g = torch.Generator().manual_seed(batch)
+    z = torch.randn([batch, G.z_dim], generator=g).to(DEV)
+    real = torch.randn([batch, 3, m['res'], m['res']], generator=g).clamp(-1, 1).to(DEV)
+    c = torch.zeros([batch, 0], device=DEV)
+    results = {}
+    for merged in (False, True):
+        loss.merge_D_passes = merged
+        D.zero_grad(set_to_none=True)
+        w_avg = G.mapping.w_avg.clone()
+        loss.accumulate_gradients(phase='Dmain', real_img=real, real_c=c, gen_z=z, gen_c=c, sync=True, gain=1)
+        G.mapping.w_avg.copy_(w_avg)
+        results[merged] = {k: p.grad.clone() for k, p in D.named_parameters()}
+    expect_merge = group is not None and group <= batch and batch % group == 0
+    assert (loss._merged_groups(batch, batch) is not None) == expect_merge
+    for k in results[False]:
+        close(results[True][k], results[False][k], 1e-4, k)
+
+
 def seeded_fill(name, shape):
     gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7fffffff)
     t = torch.randn(list(shape), generator=gen)
