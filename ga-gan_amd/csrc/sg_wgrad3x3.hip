@@ -6,7 +6,8 @@
 // A workgroup (4 waves, one per SIMD, the CU to itself: 95 KB of LDS and up to 512 registers per
 // lane) owns a 64 x 64 (cg x cx) block of dw for all 9 taps and walks the pixel tiles (8 x 32
 // pixels of one image) assigned to it; each wave accumulates a 32 x 32 sub-block (2 x 2 MFMA
-// tiles x 9 taps = 144 accumulator registers) over all 256 pixels of a tile.  Both operands are
+// tiles x 9 taps = 144 accumulator registers) over all 256 pixels of a tile (over a share of them where a
+// block side has only 32 real channels and two or four waves work on the same sub-block).  Both operands are
 // staged [pixel][channel] (160-byte rows: 128 payload + 32 pad), and the fragments - K = pixels
 // runs down the rows - are fetched with the transposing LDS read, which makes the tap shift a
 // row offset.  The packets of the next tile are loaded into registers before the multiply phase
@@ -178,7 +179,16 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
     // 4 g + 16 hf + q for the read half hf and its row q (any bijection does, as both operands use it): the two
     // lane groups one LDS cycle serves then read 8 consecutive rows, which 160-byte rows spread over all banks.
     // Lane 4q + p of a group addresses row q, channels 4p .. 4p+3 of the 16-channel tile.
-    const int wm = wave >> 1, wn = wave & 1;   // this wave's 32 x 32 sub-block of the 64 x 64 block
+    // This wave's 32 x 32 sub-block of the 64 x 64 block.  Where the block holds no more than 32 real channels on a
+    // side, the waves that would multiply padding take a share of the k-steps of the real sub-block instead (their
+    // partial sums meet in the atomics at the end).
+    int wm = wave >> 1, wn = wave & 1, ks0 = 0, ks_stride = 1;
+    {
+        const bool narrow_g = p.cg - cg0 <= 32, narrow_x = p.cx - cx0 <= 32;
+        if (narrow_g && narrow_x) { ks0 = wave; ks_stride = 4; wm = wn = 0; }
+        else if (narrow_g) { ks0 = wm; ks_stride = 2; wm = 0; }
+        else if (narrow_x) { ks0 = wn; ks_stride = 2; wn = 0; }
+    }
     const int q = lrow >> 2, pq = lrow & 3;
     int off_g[2], off_x[2];
 #pragma unroll
@@ -204,7 +214,7 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
         __syncthreads();
         if (tile + (int)gridDim.x < p.tiles_total) fetch(tile + gridDim.x);   // in flight during the multiply phase
 #pragma unroll 2
-        for (int ks = 0; ks < TH; ks++) {
+        for (int ks = ks0; ks < TH; ks += ks_stride) {
             uint4 a[2];
 #pragma unroll
             for (int m = 0; m < 2; m++) {

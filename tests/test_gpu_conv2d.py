@@ -153,6 +153,13 @@ WGRAD_CASES = [  # name, n, ci, co, h, w, k, stride, padding
     ('3x3_stride2_lowres', 9, 64, 80, 17, 24, 3, 2, 0),
     ('3x3_odd_width', 3, 48, 40, 9, 11, 3, 1, 1),               # rows that are no whole packets: scalar staging
     ('1x1_lowres', 6, 96, 64, 8, 8, 1, 1, 0),
+    # 64 x 64 blocks with at most 32 real channels on one or both sides: waves share the k-steps of the real sub-block
+    ('3x3_32_32', 2, 32, 32, 32, 64, 3, 1, 1),
+    ('3x3_32_64', 2, 32, 64, 32, 32, 3, 1, 1),
+    ('3x3_64_32', 2, 64, 32, 24, 32, 3, 1, 1),
+    ('3x3_96_96', 2, 96, 96, 16, 32, 3, 1, 1),
+    ('3x3_stride2_32_32', 2, 32, 32, 16, 64, 3, 2, 1),
+    ('3x3_stride2_32_96', 2, 32, 96, 24, 64, 3, 2, 1),
 ]
 
 
