@@ -233,23 +233,41 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
     const int lx = (tid & 7) * 8, ly = tid >> 3;   // this lane's 8 outputs: row ly, columns lx .. lx+7
     const int win = lx + (delta & ~3);             // first float4 of the lane's window
 
+    // Packet path: the packets of a plane's tile are loaded into registers one plane ahead (during the filter
+    // arithmetic and the stores of the plane before it) and converted into the LDS image when their turn comes.
+    constexpr int MAX_NV = (VEC - 1 + IN_W - 1) / VEC + 1;
+    constexpr int MAX_IT = (IN_H * MAX_NV + 255) / 256;
+    uint4 ahead[MAX_IT];
+    auto prefetch = [&](int plane) {
+        const int n = plane / p.in_c, c = plane - n * p.in_c;
+        const T* xp = x + (int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c;
+#pragma unroll
+        for (int k = 0; k < MAX_IT; k++) {
+            const int it = tid + k * 256;
+            const int ry = it / nv, v = it - ry * nv;
+            const int iy = in_y0 + ry, px0 = (vx0 + v) * VEC;
+            ahead[k] = make_uint4(0, 0, 0, 0);
+            if (it < IN_H * nv && iy >= 0 && iy < p.in_h && px0 >= 0 && px0 < p.in_w)
+                ahead[k] = *reinterpret_cast<const uint4*>(xp + (int64_t)iy * p.in_stride_h + px0);
+        }
+    };
+    if (vec_in && slot < planes) prefetch(slot);
+
     for (int plane = slot; plane < planes; plane += gridDim.y) {
         const int n = plane / p.in_c, c = plane - n * p.in_c;
         const T* xp = x + (int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c;
         T* yp = y + (int64_t)n * p.out_stride_n + (int64_t)c * p.out_stride_c;
         __syncthreads();
         if (vec_in) {
-            for (int it = tid; it < IN_H * nv; it += 256) {
+#pragma unroll
+            for (int k = 0; k < MAX_IT; k++) {
+                const int it = tid + k * 256;
+                if (it >= IN_H * nv) continue;
                 const int ry = it / nv, v = it - ry * nv;
-                const int iy = in_y0 + ry, px0 = (vx0 + v) * VEC;
+                const Pack<T> pk = __builtin_bit_cast(Pack<T>, ahead[k]);   // (an all-zero packet is zeros in every type)
                 float f[VEC];
 #pragma unroll
-                for (int j = 0; j < VEC; j++) f[j] = 0.f;
-                if (iy >= 0 && iy < p.in_h && px0 >= 0 && px0 < p.in_w) {
-                    const Pack<T> pk = load_pack(xp + (int64_t)iy * p.in_stride_h + px0);
-#pragma unroll
-                    for (int j = 0; j < VEC; j++) f[j] = (float)Elem<T>::load(pk.v[j]);
-                }
+                for (int j = 0; j < VEC; j++) f[j] = (float)Elem<T>::load(pk.v[j]);
                 float4* dst = reinterpret_cast<float4*>(s_x + ry * PITCH + v * VEC);
 #pragma unroll
                 for (int q = 0; q < VEC / 4; q++) dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
@@ -264,6 +282,24 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
             }
         }
         __syncthreads();
+        if (vec_in && plane + (int)gridDim.y < planes) prefetch(plane + gridDim.y);
+
+        const int oy = out_y0 + ly, ox = out_x0 + lx;
+        // the lane's 8 noise values, requested before the filter arithmetic that hides their latency
+        float nzv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) nzv[j] = 0.f;
+        if (has_ep && ep.noise && oy < p.out_h && ox < p.out_w) {
+            const float* nz = ep.noise + (int64_t)n * ep.noise_stride_n + (int64_t)oy * p.out_w + ox;
+            if (ox + 8 <= p.out_w && (reinterpret_cast<uintptr_t>(nz) & 15u) == 0) {
+                const float4 a = reinterpret_cast<const float4*>(nz)[0], b = reinterpret_cast<const float4*>(nz)[1];
+                nzv[0] = a.x; nzv[1] = a.y; nzv[2] = a.z; nzv[3] = a.w; nzv[4] = b.x; nzv[5] = b.y; nzv[6] = b.z; nzv[7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (ox + j < p.out_w) nzv[j] = nz[j];
+            }
+        }
 
         float acc[8];
 #pragma unroll
@@ -284,16 +320,14 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
                 for (int j = 0; j < 8; j++) acc[j] += in[j + fx + SHIFT] * tap;
             }
         }
-        const int oy = out_y0 + ly, ox = out_x0 + lx;
         if (has_ep && oy < p.out_h && ox < p.out_w) {
             const float sc = ep.scale ? ep.scale[(int64_t)n * p.in_c + c] : 1.f;
             const float bias = ep.bias ? (float)Elem<T>::load(((const T*)ep.bias)[c]) : 0.f;
             const float ng = (ep.noise && ep.noise_gain) ? *ep.noise_gain : 1.f;
-            const float* nz = ep.noise ? ep.noise + (int64_t)n * ep.noise_stride_n + (int64_t)oy * p.out_w + ox : nullptr;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 float v = acc[j] * sc + bias;
-                if (nz && ox + j < p.out_w) v += nz[j] * ng;
+                if (ep.noise) v += nzv[j] * ng;
                 if (ep.act == 3) v = (v > 0) ? v : v * ep.alpha;
                 v *= ep.gain;
                 if (ep.clamp >= 0) v = fminf(fmaxf(v, -ep.clamp), ep.clamp);
