@@ -6,6 +6,7 @@ import re
 import torch
 
 _counters = {}   # name -> float64 tensor [3] on the reporting device
+_powers = {}     # device -> float64 [[0], [1], [2]]
 _enabled = True
 
 
@@ -20,7 +21,12 @@ def report(name, value):
     elems = torch.as_tensor(value).detach().flatten().to(torch.float64)
     if elems.numel() == 0:
         return value
-    moments = torch.stack([torch.ones_like(elems).sum(), elems.sum(), elems.square().sum()])
+    powers = _powers.get(elems.device)
+    if powers is None:
+        powers = torch.tensor([[0.0], [1.0], [2.0]], dtype=torch.float64, device=elems.device)
+        if not (elems.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _powers[elems.device] = powers
+    moments = elems.unsqueeze(0).pow(powers).sum(dim=1)    # count, sum, sum of squares: two kernels
     if name in _counters and _counters[name].device == moments.device:
         _counters[name] += moments
     else:

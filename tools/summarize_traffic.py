@@ -35,7 +35,7 @@ def main():
                             fetch_bytes_per_launch=round(2.0 * f[0] / max(f[1], 1)),
                             write_bytes_per_launch=round(w[0] / max(w[1], 1)))
     json.dump(dict(note='HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2, gfx950 correction for wide reads) and '
-                        'WRITE_SIZE, separate passes of bench.py --steps 2 --warmup 1', kernels=result), open(out, 'w'), indent=1)
+                        'WRITE_SIZE, separate passes of bench.py --steps 4 --warmup 1', kernels=result), open(out, 'w'), indent=1)
     for name, v in sorted(result.items(), key=lambda kv: -kv[1]['launches'] * (kv[1]['fetch_bytes_per_launch'] + kv[1]['write_bytes_per_launch'])):
         print(f"{v['launches']:6d}  {v['fetch_bytes_per_launch'] / 1e6:9.1f} MB read  {v['write_bytes_per_launch'] / 1e6:9.1f} MB written  {name}")
 
