@@ -75,15 +75,21 @@ template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) 
            ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
 }
 
-template <class T, int STEP>
-__global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_kernel(Conv3x3Args g) {
+// WAVES = 4: the tile above.  WAVES = 8 (strided layers, whose footprint lets only one workgroup live on a CU
+// anyway): 128 output channels per workgroup - waves 4..7 multiply the same staged pixels with the second 64
+// channels, so every staged input byte feeds twice the multiplies and each SIMD holds two waves.
+template <class T, int STEP, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS_PER_CU) conv3x3_kernel(Conv3x3Args g) {
     using G = Geo<STEP>;
     constexpr int NV = G::NV, LWP = G::LWP;
+    constexpr int THREADS = 64 * WAVES, BMT = BM * (WAVES / 4);   // lanes and output channels per workgroup
+    constexpr int SLOTS = THREADS / 16, STEPS = (G::ITEMS + SLOTS - 1) / SLOTS;   // staging: item slots, items per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_in = smem;
     unsigned char* s_w = smem + G::kInBytes;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) & 3, half = tid >> 8;   // pixel rows 2 wave, 2 wave + 1 of the tile; channels 64 half ..
     const int lrow = lane & 15, lgrp = lane >> 4;
 
     // ---- which tile: workgroups are dealt to the 8 XCDs round-robin; XCD k takes the k-th contiguous eighth of the
@@ -94,7 +100,7 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
     const int tb = unit % g.tiles_b; unit /= g.tiles_b;
     const int ta = unit % g.tiles_a; unit /= g.tiles_a;
     const int n = unit % g.n;
-    const int m0 = (unit / g.n) * BM;
+    const int m0 = (unit / g.n) * BMT;
     const int a0 = ta * TH, b0 = tb * TW;
     const int plane = g.h * g.wid;
     const T* __restrict__ x = (const T*)g.x + (unsigned)(n * g.ci * plane);   // fewer than 2^31 elements per tensor
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
     const int cg = tid & 15, slot0 = tid >> 4;
     const int px_first = b0 * STEP + g.px_shift;                    // first pixel column of the staged packets
     const int iy_first = a0 * STEP + g.dy0;
-    uint4 va[G::STEPS], vb[G::STEPS], vw[9];
+    uint4 va[STEPS], vb[STEPS], vw[9];
     float s0 = 1.f, s1 = 1.f;
 
     auto fetch = [&](int c0) {
@@ -112,8 +118,8 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
         const bool c_ok = c < g.ci, two = c + 1 < g.ci;
         const T* src0 = x + (unsigned)(c * plane);
 #pragma unroll
-        for (int q = 0; q < G::STEPS; q++) {
-            const int item = slot0 + 16 * q;
+        for (int q = 0; q < STEPS; q++) {
+            const int item = slot0 + SLOTS * q;
             const int ry = item / NV, v = item - ry * NV;
             const int iy = iy_first + ry, px0 = px_first + v * 8;
             va[q] = make_uint4(0, 0, 0, 0);
@@ -128,7 +134,7 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
             s0 = (c < g.ci) ? g.in_scale[n * g.ci + c] : 0.f;
             s1 = (c + 1 < g.ci) ? g.in_scale[n * g.ci + c + 1] : 0.f;
         }
-        // weights [tap][co][ci]: packet e = tid + 256 q is tap q, output channel tid >> 2, 16-byte slot tid & 3
+        // weights [tap][co][ci]: packet e = tid + THREADS q is tap q, output channel tid >> 2, 16-byte slot tid & 3
         const int o = m0 + (tid >> 2), cw = c0 + (tid & 3) * 8;
         const bool w_ok = o < g.co && cw < g.ci;
 #pragma unroll
@@ -140,8 +146,8 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
 
     auto commit = [&]() {
 #pragma unroll
-        for (int q = 0; q < G::STEPS; q++) {
-            const int item = slot0 + 16 * q;
+        for (int q = 0; q < STEPS; q++) {
+            const int item = slot0 + SLOTS * q;
             if (item >= G::ITEMS) continue;
             const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
             const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
             }
         }
 #pragma unroll
-        for (int q = 0; q < 9; q++) *reinterpret_cast<uint4*>(s_w + swz(q * BM + (tid >> 2), (tid & 3) * 16)) = vw[q];
+        for (int q = 0; q < 9; q++) *reinterpret_cast<uint4*>(s_w + swz(q * BMT + (tid >> 2), (tid & 3) * 16)) = vw[q];
     };
 
     // ---- multiply-phase addressing ----------------------------------------------------------------------
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
     float sc[4], bs[4];
     float4 nz[4];
     uint2 rx[4][4];
-    const int ch0 = m0 + lrow;
+    const int ch0 = m0 + 64 * half + lrow;
     const int ch_stride = 16 * g.oh * g.ow;
     unsigned off0[4];
     bool inside[4];
@@ -214,7 +220,7 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
     auto read_tap = [&](int tap, uint4 (&a)[4], uint4 (&b)[4]) {
         const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const uint4*>(s_w + (tap * BM + m * 16) * kRow + a_lane);
+        for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const uint4*>(s_w + (tap * BMT + 64 * half + m * 16) * kRow + a_lane);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int row = brow[j] + ky * LWP + kx;
@@ -280,11 +286,11 @@ __global__ void __launch_bounds__(kThreads, Geo<STEP>::BLOCKS_PER_CU) conv3x3_ke
             float r = red[m];
             r += __shfl_xor(r, 16, 64);
             r += __shfl_xor(r, 32, 64);
-            if (lgrp == 0) s_red[wave * BM + m * 16 + lrow] = r;
+            if (lgrp == 0) s_red[wave * BMT + 64 * half + m * 16 + lrow] = r;
         }
         __syncthreads();
-        if (tid < BM && m0 + tid < g.co) {
-            const float r = s_red[tid] + s_red[BM + tid] + s_red[2 * BM + tid] + s_red[3 * BM + tid];
+        if (tid < BMT && m0 + tid < g.co) {
+            const float r = s_red[tid] + s_red[BMT + tid] + s_red[2 * BMT + tid] + s_red[3 * BMT + tid];
             g.reduce_out[((n * g.tiles_a + ta) * g.tiles_b + tb) * g.co + m0 + tid] = r;
         }
     }
@@ -560,14 +566,25 @@ static int launch_resident_for(const Conv3x3Args& g, int64_t units, int ci, int 
     return narrow ? launch_resident<T, 2, 2>(g, units, stream) : launch_resident<T, 2, 4>(g, units, stream);
 }
 
-template <class T, int STEP>
-static int launch_step(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
-    constexpr size_t lds = Geo<STEP>::kInBytes + kWBytes;
-    auto kernel = conv3x3_kernel<T, STEP>;
+template <class T, int STEP, int WAVES = 4>
+static int launch_step(Conv3x3Args g, hipStream_t stream) {
+    constexpr int BMT = BM * (WAVES / 4);
+    constexpr size_t lds = Geo<STEP>::kInBytes + kWBytes * (WAVES / 4);
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS of a CU");
+    const int64_t units = (int64_t)g.tiles_a * g.tiles_b * g.n * ((g.co + BMT - 1) / BMT);
+    SG_REQUIRE(units <= INT32_MAX - 8, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
+    g.units = (int)units;
+    auto kernel = conv3x3_kernel<T, STEP, WAVES>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 7) / 8 * 8)), dim3(kThreads), lds, stream, g);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 7) / 8 * 8)), dim3(64 * WAVES), lds, stream, g);
     return check_launch("sg_conv2d");
+}
+
+// Strided layers with at least 128 output channels take the 8-wave form.
+template <class T>
+static int launch_strided(const Conv3x3Args& g, hipStream_t stream) {
+    return (g.co > BM) ? launch_step<T, 2, 8>(g, stream) : launch_step<T, 2, 4>(g, stream);
 }
 
 int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
@@ -596,8 +613,8 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
         return (p.dtype == SG_BF16) ? launch_resident_for<__hip_bfloat16>(g, units, p.ci, p.co, stream)
                                     : launch_resident_for<__half>(g, units, p.ci, p.co, stream);
     if (p.dtype == SG_BF16)
-        return (p.in_step == 1) ? launch_step<__hip_bfloat16, 1>(g, units, stream) : launch_step<__hip_bfloat16, 2>(g, units, stream);
-    return (p.in_step == 1) ? launch_step<__half, 1>(g, units, stream) : launch_step<__half, 2>(g, units, stream);
+        return (p.in_step == 1) ? launch_step<__hip_bfloat16, 1>(g, stream) : launch_strided<__hip_bfloat16>(g, stream);
+    return (p.in_step == 1) ? launch_step<__half, 1>(g, stream) : launch_strided<__half>(g, stream);
 }
 
 }  // namespace sg
