@@ -75,9 +75,9 @@ template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) 
            ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
 }
 
-// WAVES = 4: the tile above.  WAVES = 8 (strided layers, whose footprint lets only one workgroup live on a CU
-// anyway): 128 output channels per workgroup - waves 4..7 multiply the same staged pixels with the second 64
-// channels, so every staged input byte feeds twice the multiplies and each SIMD holds two waves.
+// WAVES = 4: the tile above.  WAVES = 8 (layers with more than 64 output channels): 128 output channels per
+// workgroup - waves 4..7 multiply the same staged pixels with the second 64 channels, so every staged input byte
+// feeds twice the multiplies; one such workgroup per CU, two waves per SIMD.
 template <class T, int STEP, int WAVES = 4>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS_PER_CU) conv3x3_kernel(Conv3x3Args g) {
     using G = Geo<STEP>;
@@ -581,9 +581,10 @@ static int launch_step(Conv3x3Args g, hipStream_t stream) {
     return check_launch("sg_conv2d");
 }
 
-// Strided layers with at least 128 output channels take the 8-wave form.
+// Layers with more than 64 output channels take the 8-wave form (128 channels per workgroup).
 template <class T>
-static int launch_strided(const Conv3x3Args& g, hipStream_t stream) {
+static int launch_wide_or_not(const Conv3x3Args& g, int step, hipStream_t stream) {
+    if (step == 1) return (g.co > BM) ? launch_step<T, 1, 8>(g, stream) : launch_step<T, 1, 4>(g, stream);
     return (g.co > BM) ? launch_step<T, 2, 8>(g, stream) : launch_step<T, 2, 4>(g, stream);
 }
 
@@ -612,9 +613,8 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     if (conv3x3_resident(p))
         return (p.dtype == SG_BF16) ? launch_resident_for<__hip_bfloat16>(g, units, p.ci, p.co, stream)
                                     : launch_resident_for<__half>(g, units, p.ci, p.co, stream);
-    if (p.dtype == SG_BF16)
-        return (p.in_step == 1) ? launch_step<__hip_bfloat16, 1>(g, stream) : launch_strided<__hip_bfloat16>(g, stream);
-    return (p.in_step == 1) ? launch_step<__half, 1>(g, stream) : launch_strided<__half>(g, stream);
+    if (p.dtype == SG_BF16) return launch_wide_or_not<__hip_bfloat16>(g, p.in_step, stream);
+    return launch_wide_or_not<__half>(g, p.in_step, stream);
 }
 
 }  // namespace sg
