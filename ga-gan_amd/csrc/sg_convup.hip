@@ -71,12 +71,17 @@ struct ConvUpArgs {
     int tiles_a, tiles_b, units;
 };
 
-template <class T>
-__global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
+// WAVES = 8 (layers with more than 32 output channels): 64 output channels per workgroup - waves 4..7 multiply the
+// same staged pixels with the second 32 channels; one such workgroup per CU, two waves per SIMD.
+template <class T, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) conv_up2_kernel(ConvUpArgs g) {
+    constexpr int BCOT = BCO * (WAVES / 4);                                    // output channels per workgroup
+    constexpr int SLOTS = 4 * WAVES, STEPS = (ITEMS + SLOTS - 1) / SLOTS;      // staging: item slots, items per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_in = smem;
     unsigned char* s_w = smem + kInBytes;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) & 3, half = tid >> 8;   // tile rows 2 wave, 2 wave + 1; channels 32 half ..
     const int lrow = lane & 15, lgrp = lane >> 4;
 
     // XCD k (workgroups k, k + 8, ...) takes the k-th contiguous eighth of the units: neighbouring tiles share an L2
@@ -86,14 +91,14 @@ __global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
     const int tb = unit % g.tiles_b; unit /= g.tiles_b;
     const int ta = unit % g.tiles_a; unit /= g.tiles_a;
     const int n = unit % g.n;
-    const int m0 = (unit / g.n) * BCO;
+    const int m0 = (unit / g.n) * BCOT;
     const int a0 = ta * TH, b0 = tb * TW;
     const int plane = g.h * g.wid;
     const T* __restrict__ x = (const T*)g.x + (unsigned)(n * g.ci * plane);
     const T* __restrict__ w = (const T*)g.w;
 
     const int cg = tid & 15, slot0 = tid >> 4;
-    uint4 va[IN_STEPS], vb[IN_STEPS];
+    uint4 va[STEPS], vb[STEPS];
     float s0 = 1.f, s1 = 1.f;
 
     auto fetch = [&](int c0) {
@@ -101,8 +106,8 @@ __global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
         const bool c_ok = c < g.ci, two = c + 1 < g.ci;
         const T* src0 = x + (unsigned)(c * plane);
 #pragma unroll
-        for (int q = 0; q < IN_STEPS; q++) {
-            const int item = slot0 + 16 * q;
+        for (int q = 0; q < STEPS; q++) {
+            const int item = slot0 + SLOTS * q;
             const int ry = item / NV, v = item - ry * NV;
             const int iy = a0 - 1 + ry, px0 = b0 - 8 + v * 8;
             va[q] = make_uint4(0, 0, 0, 0);
@@ -120,8 +125,8 @@ __global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int q = 0; q < IN_STEPS; q++) {
-            const int item = slot0 + 16 * q;
+        for (int q = 0; q < STEPS; q++) {
+            const int item = slot0 + SLOTS * q;
             if (item >= ITEMS) continue;
             const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
             const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
@@ -142,8 +147,8 @@ __global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
         constexpr Combo kc[kCombos + 1] = {{0, 0, 0, -1, -1}, {0, 0, 1, -1, 0}, {0, 1, 0, 0, -1}, {0, 1, 1, 0, 0}, {1, 0, 0, -1, 0},
                                            {1, 1, 0, 0, 0}, {2, 0, 0, 0, -1}, {2, 0, 1, 0, 0}, {3, 0, 0, 0, 0}, {3, 0, 0, 0, 0}};
         constexpr int nkx[4] = {2, 1, 2, 1};
-        const bool odd = tid >= 128;
-        const int o_local = (tid >> 2) & 31, slot = tid & 3;
+        const bool odd = (tid & 255) >= 128;
+        const int o_local = ((tid >> 2) & 31) + 32 * half, slot = tid & 3;
         const int o = m0 + o_local, cw = c0 + slot * 8;
         const bool ok = o < g.co && cw < g.ci;
 #pragma unroll
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
             if (combo >= kCombos) continue;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) v = *reinterpret_cast<const uint4*>(w + (unsigned)(w_off + (tap * g.co + o) * g.ci + cw));
-            *reinterpret_cast<uint4*>(s_w + swz(combo * BCO + o_local, slot * 16)) = v;
+            *reinterpret_cast<uint4*>(s_w + swz(combo * BCOT + o_local, slot * 16)) = v;
         }
     };
 
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
                 const int p = kc[combo].phase;
                 uint4 fa[2];
 #pragma unroll
-                for (int ct = 0; ct < 2; ct++) fa[ct] = *reinterpret_cast<const uint4*>(s_w + (combo * BCO + ct * 16) * kRow + a_lane);
+                for (int ct = 0; ct < 2; ct++) fa[ct] = *reinterpret_cast<const uint4*>(s_w + (combo * BCOT + 32 * half + ct * 16) * kRow + a_lane);
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -226,7 +231,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv_up2_kernel(ConvUpArgs g) {
             if (oy >= g.oh) continue;
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
-                const int ch = m0 + ct * 16 + lrow;
+                const int ch = m0 + 32 * half + ct * 16 + lrow;
                 if (ch >= g.co) continue;
                 const f32x4_t e = acc[2 * py][ct][j], o = acc[2 * py + 1][ct][j];
                 const uint4 out = make_uint4(pack16<T>(e[0], o[0]), pack16<T>(e[1], o[1]), pack16<T>(e[2], o[2]), pack16<T>(e[3], o[3]));
@@ -270,12 +275,20 @@ int conv_up2_launch(const sg_conv2d_params& p, hipStream_t stream) {
     g.w_offset2 = (int)p.phase[2].w_offset; g.w_offset3 = (int)p.phase[3].w_offset;
     g.tiles_a = ((p.oh + 1) / 2 + TH - 1) / TH;
     g.tiles_b = ((p.ow + 1) / 2 + TW - 1) / TW;
-    const int64_t units = (int64_t)g.tiles_a * g.tiles_b * p.n * ((p.co + BCO - 1) / BCO);
+    const bool wide = p.co > BCO;
+    const int bco = wide ? 2 * BCO : BCO;
+    const int64_t units = (int64_t)g.tiles_a * g.tiles_b * p.n * ((p.co + bco - 1) / bco);
     SG_REQUIRE(units <= INT32_MAX - 8, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     g.units = (int)units;
-    constexpr size_t lds = kInBytes + kWBytes;
-    auto kernel = (p.dtype == SG_BF16) ? conv_up2_kernel<__hip_bfloat16> : conv_up2_kernel<__half>;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 7) / 8 * 8)), dim3(kThreads), lds, stream, g);
+    const size_t lds = kInBytes + kWBytes * (wide ? 2 : 1);   // 59904 at most: below the 64 KB that need no opt-in
+    const dim3 grid((unsigned)((units + 7) / 8 * 8));
+    if (p.dtype == SG_BF16) {
+        if (wide) hipLaunchKernelGGL((conv_up2_kernel<__hip_bfloat16, 8>), grid, dim3(512), lds, stream, g);
+        else hipLaunchKernelGGL((conv_up2_kernel<__hip_bfloat16, 4>), grid, dim3(256), lds, stream, g);
+    } else {
+        if (wide) hipLaunchKernelGGL((conv_up2_kernel<__half, 8>), grid, dim3(512), lds, stream, g);
+        else hipLaunchKernelGGL((conv_up2_kernel<__half, 4>), grid, dim3(256), lds, stream, g);
+    }
     return check_launch("sg_conv2d");
 }
 
