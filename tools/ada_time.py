@@ -1,5 +1,11 @@
-import torch, time, sys
-sys.path.insert(0, '/root/repo')
+"""Time the augmentation pipe alone (forward + backward, and forward only) at the bench batch."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ga_gan_amd.training.training_loop import make_augment_pipe
 from ga_gan_amd.torch_utils.ops import grid_sample_gradfix
 grid_sample_gradfix.enabled = True
