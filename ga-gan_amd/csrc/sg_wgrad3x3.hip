@@ -3,8 +3,8 @@
 // GEMM view per tap: M = cg, N = cx, K = pixels.  Same contract as conv2d_wgrad_kernel of
 // sg_conv2d.hip, which sg_conv2d_wgrad falls back to for every other geometry.
 //
-// A workgroup (4 waves, one per SIMD, the CU to itself: 95 KB of LDS and up to 512 registers per
-// lane) owns a 64 x 64 (cg x cx) block of dw for all 9 taps and walks the pixel tiles (8 x 32
+// A workgroup (the CU to itself: 95-114 KB of LDS; 4 waves, one per SIMD, with up to 512 registers per lane at
+// stride 2, 8 waves at unit stride - see WAVES below) owns a 64 x 64 (cg x cx) block of dw for all 9 taps and walks the pixel tiles (8 x 32
 // pixels of one image) assigned to it; each wave accumulates a 32 x 32 sub-block (2 x 2 MFMA
 // tiles x 9 taps = 144 accumulator registers) over all 256 pixels of a tile (over a share of them where a
 // block side has only 32 real channels and two or four waves work on the same sub-block).  Both operands are
@@ -77,14 +77,18 @@ struct Wgrad3x3Args {
     int tiles_a, tiles_b, tiles_total;
 };
 
-template <class T, int STEP>
-__global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
+// WAVES = 8: waves 4..7 work on the sub-blocks of waves 0..3 and take every other k-step of theirs (two waves per
+// SIMD: one's LDS reads and staging arithmetic run under the other's multiplies; the partial sums meet in the atomics).
+template <class T, int STEP, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
     using G = WGeo<STEP>;
-    constexpr int TH = G::TH, LH = G::LH, LW = G::LW, NV = G::NV, X_STEPS = G::X_STEPS, G_STEPS = G::G_STEPS;
+    constexpr int TH = G::TH, LH = G::LH, LW = G::LW, NV = G::NV;
+    constexpr int ROWS = 2 * WAVES;                                   // item rows staged per step (32 lanes per row)
+    constexpr int X_STEPS = (LH * NV + ROWS - 1) / ROWS, G_STEPS = (TH * (TW / 8) + ROWS - 1) / ROWS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_x = smem;
     unsigned char* s_g = smem + G::kXBytes;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, k_half = tid >> 8;
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int cg0 = blockIdx.y * BC, cx0 = blockIdx.z * BC;
     const T* __restrict__ x = (const T*)p.x;
@@ -107,7 +111,7 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
             const T* base = x + (unsigned)((n * p.cx + c) * x_plane);
 #pragma unroll
             for (int s = 0; s < X_STEPS; s++) {
-                const int r = (tid >> 5) + 8 * s;          // item row index = ry * NV + v
+                const int r = (tid >> 5) + ROWS * s;          // item row index = ry * NV + v
                 const int v = r % NV, ry = r / NV;
                 const int iy = a0 * STEP + p.dy0 + ry, px0 = b0 * STEP + p.px_shift + v * 8;
                 xa[s] = make_uint4(0, 0, 0, 0);
@@ -129,12 +133,12 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
             const T* base = g + (unsigned)((n * p.cg + c) * g_plane);
 #pragma unroll
             for (int s = 0; s < G_STEPS; s++) {
-                const int r = (tid >> 5) + 8 * s;          // = ra * 4 + v
+                const int r = (tid >> 5) + ROWS * s;          // = ra * 4 + v
                 const int v = r & 3, ra = r >> 2;
                 const int a = a0 + ra, b = b0 + v * 8;
                 ga[s] = make_uint4(0, 0, 0, 0);
                 gb[s] = make_uint4(0, 0, 0, 0);
-                if (c_ok && a < p.gh && b < p.gw) {
+                if (c_ok && ra < TH && a < p.gh && b < p.gw) {
                     const T* src = base + a * p.gw + b;
                     ga[s] = *reinterpret_cast<const uint4*>(src);
                     if (two) gb[s] = *reinterpret_cast<const uint4*>(src + g_plane);
@@ -162,14 +166,15 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
     auto commit = [&]() {
 #pragma unroll
         for (int s = 0; s < X_STEPS; s++) {
-            const int r = (tid >> 5) + 8 * s;
+            const int r = (tid >> 5) + ROWS * s;
             const int v = r % NV, ry = r / NV;
             if (ry < LH) put8(s_x + ry * LW * kPitch, xa[s], xb[s], p.x_scale != nullptr, xs0, xs1, v * 8 - p.px_col, LW);
         }
 #pragma unroll
         for (int s = 0; s < G_STEPS; s++) {
-            const int r = (tid >> 5) + 8 * s;
+            const int r = (tid >> 5) + ROWS * s;
             const int v = r & 3, ra = r >> 2;
+            if (ra >= TH) continue;
             put8(s_g + ra * TW * kPitch, ga[s], gb[s], p.g_scale != nullptr, gs0, gs1, v * 8, TW);
         }
     };
@@ -188,6 +193,7 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
         if (narrow_g && narrow_x) { ks0 = wave; ks_stride = 4; wm = wn = 0; }
         else if (narrow_g) { ks0 = wm; ks_stride = 2; wm = 0; }
         else if (narrow_x) { ks0 = wn; ks_stride = 2; wn = 0; }
+        if (WAVES == 8) { ks0 = 2 * ks0 + k_half; ks_stride *= 2; }
     }
     const int q = lrow >> 2, pq = lrow & 3;
     int off_g[2], off_x[2];
@@ -276,10 +282,11 @@ static int launch_wstep(Wgrad3x3Args& a, const sg_conv2d_wgrad_params& p, hipStr
     if (split > tiles) split = tiles;
     if (split < 1) split = 1;
     constexpr size_t lds = G::kXBytes + G::kGBytes;
-    auto kernel = wgrad3x3_kernel<T, STEP>;
+    constexpr int WAVES = (STEP == 1) ? 8 : 4;   // (the strided form spills registers with two waves per SIMD and loses)
+    auto kernel = wgrad3x3_kernel<T, STEP, WAVES>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)split, (unsigned)blocks_g, (unsigned)blocks_x), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)split, (unsigned)blocks_g, (unsigned)blocks_x), dim3(64 * WAVES), lds, stream, a);
     return check_launch("sg_conv2d_wgrad");
 }
 
