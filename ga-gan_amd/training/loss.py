@@ -14,7 +14,8 @@ from ..torch_utils.ops import conv2d_gradfix
 
 def _interleave(a, b, groups):
     """[n, ...] x 2 -> [2n, ...]: rows split into `groups` runs; run g of a, then run g of b, for g = 0, 1, ..."""
-    return torch.cat([a.unflatten(0, (groups, -1)), b.unflatten(0, (groups, -1))], dim=1).flatten(0, 1)
+    run = a.shape[0] // groups
+    return torch.cat([a.unflatten(0, (groups, run)), b.unflatten(0, (groups, run))], dim=1).flatten(0, 1)
 
 
 class Loss:
@@ -136,7 +137,7 @@ class StyleGAN2Loss(Loss):
                 else:
                     real_aug = real_img.detach()
                 logits = self.D(_interleave(gen_img, real_aug, groups), _interleave(gen_c, real_c, groups))
-                per_group = logits.unflatten(0, (groups, -1))
+                per_group = logits.unflatten(0, (groups, logits.shape[0] // groups))
                 half = per_group.shape[1] // 2
                 gen_logits, real_logits = per_group[:, :half].flatten(0, 1), per_group[:, half:].flatten(0, 1)
                 training_stats.report('Loss/scores/fake', gen_logits)
