@@ -23,7 +23,7 @@ def report(name, value):
         return value
     powers = _powers.get(elems.device)
     if powers is None:
-        powers = torch.tensor([[0.0], [1.0], [2.0]], dtype=torch.float64, device=elems.device)
+        powers = torch.arange(3, dtype=torch.float64, device=elems.device).reshape(3, 1)   # (a kernel, not a copy: legal under stream capture)
         if not (elems.is_cuda and torch.cuda.is_current_stream_capturing()):
             _powers[elems.device] = powers
     moments = elems.unsqueeze(0).pow(powers).sum(dim=1)    # count, sum, sum of squares: two kernels
