@@ -111,12 +111,18 @@ _DETAIL = bool(os.environ.get('SG_PROFILE_DETAIL'))   # profiling labels carry t
 _DTYPE_NAME = {torch.float32: 'float', torch.float16: '__half', torch.bfloat16: '__hip_bfloat16'}
 
 
+REDUCED_MAX_PARTIALS = 1 << 20   # SG_CONV2D_REDUCED_MAX_PARTIALS of include/sg_ops.h
+
+
 def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
-           act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None, reduce_x=None):
+           act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None, reduce_x=None, out=None, reduce_sum=None):
     """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow].
     `out_hw` overrides the plan's natural output size (pixels whose taps all fall outside x are zero).
     With `reduce_x` (y's shape and dtype) the call returns (y, r), r[n, co] = sum over pixels of
-    reduce_x * (the contraction before out_scale and the epilogue), float32."""
+    reduce_x * (the contraction before out_scale and the epilogue), float32.
+    With `out` (and, for a reduction, `reduce_sum` [n, co] float32) given, the results are written there and the
+    call allocates no device memory: the reduction then runs through `sg_conv2d_reduced`, whose partial sums live
+    in a fixed array inside the library (at most REDUCED_MAX_PARTIALS of them, one call at a time per device)."""
     if not x.is_cuda:
         raise RuntimeError('x must reside on CUDA device')
     if x.dim() != 4 or not x.is_contiguous():
@@ -145,9 +151,15 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
             raise RuntimeError('noise must hold one plane, or one plane per sample')
     if noise_gain is not None and (noise_gain.dtype != torch.float32 or noise_gain.numel() != 1):
         raise RuntimeError('noise_gain must be a float32 scalar tensor')
-    y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device)
+    if out is not None:
+        if tuple(out.shape) != (n, co, oh, ow) or out.dtype != x.dtype or out.device != x.device or not out.is_contiguous():
+            raise RuntimeError(f'out must be a dense {x.dtype} tensor of shape {(n, co, oh, ow)} on x\'s device')
+        if reduce_x is not None and (reduce_sum is None or reduce_sum.dtype != torch.float32 or tuple(reduce_sum.shape) != (n, co)
+                                     or reduce_sum.device != x.device or not reduce_sum.is_contiguous()):
+            raise RuntimeError(f'reduce_sum must be a dense float32 tensor of shape {(n, co)} on x\'s device')
+    y = out if out is not None else torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device)
     if y.numel() == 0:
-        return y
+        return y if reduce_x is None else (y, reduce_sum if out is not None else torch.zeros([n, co], device=x.device))
     if reduce_x is not None and (reduce_x.shape != y.shape or reduce_x.dtype != x.dtype or not reduce_x.is_contiguous()):
         raise RuntimeError('reduce_x must be dense and match the output')
     p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(w_packed), y=_lib.ptr(y), in_scale=_lib.ptr(in_scale),
@@ -161,6 +173,12 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
         offset += nky * nkx * co * ci
     partial = None
+    if reduce_x is not None and out is not None:
+        label = f'{_lib.lib().sg_conv2d_kernel(ctypes.byref(p)).decode()}<{_DTYPE_NAME[x.dtype]}>' if _lib.profiling() else ''
+        fn = _lib.lib().sg_conv2d_reduced
+        _lib.launch_raw(lambda stream: fn(ctypes.byref(p), _lib.ptr(reduce_sum), stream), x, 'sg_conv2d_reduced', label,
+                        _lib.nbytes(x, y, reduce_x))
+        return y, reduce_sum
     if reduce_x is not None:
         rows = _lib.lib().sg_conv2d_reduce_rows(ctypes.byref(p))
         if rows < 1:

@@ -36,6 +36,7 @@
 #include "sg_conv3x3.h"
 
 #include <algorithm>
+#include <atomic>
 
 namespace sg {
 namespace {
@@ -1126,4 +1127,80 @@ extern "C" const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p) {
     if (p == nullptr) return "";
     if (sg::wgrad3x3_eligible(*p)) return "wgrad3x3_kernel";
     return sg::wgrad_f32_eligible(*p) ? "wgrad_f32_kernel" : "conv2d_wgrad_kernel";
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sg_conv2d_reduced: sg_conv2d with the style-gradient reduction finished on the device, for callers that may
+// not allocate (stream capture, serving loops).  The partial rows that sg_conv2d leaves in a caller-provided
+// workspace go to a fixed array in device memory instead, and one more kernel adds them up.
+namespace sg {
+namespace {
+
+constexpr int64_t kScratchFloats = SG_CONV2D_REDUCED_MAX_PARTIALS;   // 4 MiB on every device the library runs on
+static __device__ __align__(256) float scratch[kScratchFloats];
+
+// Device address of `scratch` on the current device (every device holds its own copy of the array); resolved once
+// per device.  Returns nullptr and sets the error text on failure.
+float* scratch_address() {
+    static std::atomic<float*> cached[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) {
+        fail((int)(e != hipSuccess ? e : hipErrorInvalidDevice), "conv2d_reduced: no usable current device");
+        return nullptr;
+    }
+    float* ptr = cached[dev].load(std::memory_order_acquire);
+    if (ptr == nullptr) {
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || ptr == nullptr) {
+            fail((int)(e != hipSuccess ? e : hipErrorInvalidSymbol), "conv2d_reduced: cannot resolve the scratch array: %s",
+                 hipGetErrorString(e));
+            return nullptr;
+        }
+        cached[dev].store(ptr, std::memory_order_release);
+    }
+    return ptr;
+}
+
+// out[n, c] = sum over rows of partial[n, row, c]; one lane per (n, c), rows added in order.
+__global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int rows, int c) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * c) return;
+    const int64_t img = i / c, ch = i - img * c;
+    const float* src = partial + img * rows * c + ch;
+    float s = 0.f;
+    for (int r = 0; r < rows; r++) s += src[(int64_t)r * c];
+    out[i] = s;
+}
+
+}  // namespace
+}  // namespace sg
+
+extern "C" int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t stream) {
+    using namespace sg;
+    SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
+    SG_REQUIRE(p->reduce_x != nullptr && reduce_sum != nullptr, SG_ERR_NULL_POINTER,
+               "conv2d_reduced: reduce_x and reduce_sum must not be NULL");
+    SG_REQUIRE(p->reduce_out == nullptr, SG_ERR_INVALID_ARGUMENT,
+               "conv2d_reduced: reduce_out must be NULL (the partial rows live in the library's own array)");
+    SG_REQUIRE(p->n >= 0 && p->co >= 1, SG_ERR_INVALID_ARGUMENT, "conv2d: bad tensor sizes");
+    if (p->n == 0) return SG_OK;
+    const int rows = sg_conv2d_reduce_rows(p);
+    SG_REQUIRE(rows >= 1, SG_ERR_INVALID_ARGUMENT, "conv2d_reduced: bad geometry");
+    const int64_t partials = (int64_t)p->n * rows * p->co;
+    SG_REQUIRE(partials <= kScratchFloats, SG_ERR_UNSUPPORTED,
+               "conv2d_reduced: %lld partial sums (n %d x %d rows x %d channels) exceed the fixed array of %lld; use sg_conv2d "
+               "with a workspace", (long long)partials, p->n, rows, p->co, (long long)kScratchFloats);
+    float* ws = scratch_address();
+    if (ws == nullptr) return SG_ERR_UNSUPPORTED;
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)partials * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "conv2d_reduced: clearing the scratch array failed: %s", hipGetErrorString(e));
+    sg_conv2d_params q = *p;
+    q.reduce_out = ws;
+    const int rc = sg_conv2d(&q, stream);
+    if (rc != SG_OK) return rc;
+    const int64_t lanes = (int64_t)p->n * p->co;
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, reduce_sum, p->n, rows, p->co);
+    return check_launch("sg_conv2d_reduced");
 }

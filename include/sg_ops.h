@@ -229,6 +229,17 @@ int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
 /* Number of partial rows per sample the reduction above writes for this geometry (>= 1), -1 on a bad argument. */
 int sg_conv2d_reduce_rows(const sg_conv2d_params* p);
 
+/* sg_conv2d with a reduction (p->reduce_x set) for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The
+ * partial rows go to a fixed array inside the library (SG_CONV2D_REDUCED_MAX_PARTIALS floats, one copy per
+ * device, held until the process ends) instead of a caller-provided workspace, and are added up on the device:
+ *   reduce_sum[n, co] (float32, written, not accumulated) = sum over pixels of reduce_x * contraction.
+ * p->reduce_out must be NULL.  The call allocates and frees nothing; it is rejected with SG_ERR_UNSUPPORTED when
+ * n * sg_conv2d_reduce_rows(p) * co exceeds the array.  Every call on a device shares that device's array: calls
+ * whose execution may overlap on one device (different streams) race; calls on one stream are safe. */
+#define SG_CONV2D_REDUCED_MAX_PARTIALS (1 << 20)
+int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t stream);
+
 /* Name of the device kernel sg_conv2d runs for this geometry (the symbol a profiler reports, without template
  * arguments).  For 16-bit tensors whose rows are whole aligned packets: "conv3x3_kernel" (3x3, output step 1,
  * input step 1 or 2), "conv3x3_resident_kernel" (the same with at most 64 channels on both sides: the weights

@@ -1,0 +1,58 @@
+"""The entry point that allocates nothing (`sg_conv2d_reduced`) against `sg_conv2d` with a caller-provided
+workspace, through the C ABI, on two calls in a row (the second smaller, so stale partial sums of the first
+would show).  The convolution output comes from the same kernel and must be bit-identical; the reduced sums are
+the same float32 partial sums added in a different order: 1e-5 of the largest sum.  Run with -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _run(cp, n, ci, co, h, w, dtype, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn([n, ci, h, w], device=DEV, generator=g).to(dtype)
+    wt = (torch.randn([co, ci, 3, 3], device=DEV, generator=g) / (ci * 9) ** 0.5).to(dtype)
+    s = torch.rand([n, co], device=DEV, generator=g) + 0.5
+    rx = torch.randn([n, co, h, w], device=DEV, generator=g).to(dtype)
+    plan = cp.plan_conv(3, 3, padding=1)
+    packed = plan.pack(wt)
+    y0, r0 = cp.conv2d(x, packed, plan, co, out_scale=s, reduce_x=rx)
+    out = torch.full_like(y0, float('nan'))
+    rsum = torch.full([n, co], float('nan'), device=DEV)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_stats()['allocation.all.allocated']
+    y1, r1 = cp.conv2d(x, packed, plan, co, out_scale=s, reduce_x=rx, out=out, reduce_sum=rsum)
+    assert torch.cuda.memory_stats()['allocation.all.allocated'] == before, 'the call allocated device memory through torch'
+    assert y1 is out and r1 is rsum
+    assert torch.equal(y1, y0)
+    scale = float(r0.abs().max())
+    assert float((r1 - r0).abs().max()) <= 1e-5 * scale, (float((r1 - r0).abs().max()), scale)
+    # and against float64 arithmetic on the host: sum over pixels of reduce_x * conv(x, w)
+    want = (torch.nn.functional.conv2d(x.double().cpu(), wt.double().cpu(), padding=1) * rx.double().cpu()).sum(dim=(2, 3))
+    assert float((r1.double().cpu() - want).abs().max()) <= 2e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_conv2d_reduced_twice_second_smaller(dtype):
+    from ga_gan_amd import conv2d_plugin as cp
+    _run(cp, 3, 64, 64, 48, 64, dtype, 1)     # 3 x 12 rows x 64 channels of partial sums
+    _run(cp, 2, 32, 32, 16, 32, dtype, 2)     # fewer samples, rows and channels: must not see the first call's sums
+    _run(cp, 5, 64, 32, 4, 4, dtype, 3)       # several samples per tile: the kernel adds into the array with atomics
+
+
+def test_conv2d_reduced_rejects_oversize_and_bad_arguments():
+    import ctypes
+    from ga_gan_amd import _lib, conv2d_plugin as cp
+    plan = cp.plan_conv(3, 3, padding=1)
+    n, c, h = 16, 128, 512                    # 16 x (64 x 16) rows x 128 channels = 2^21 partial sums > 2^20
+    x = torch.zeros([1], device=DEV)
+    p = cp.Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(x), y=_lib.ptr(x), reduce_x=_lib.ptr(x), dtype=2, n=n, ci=c, h=h, w_in=h,
+                        co=c, oh=h, ow=h, in_step=1, out_step=1, num_phases=1, act=1, gain=1.0, clamp=-1.0)
+    p.phase[0] = cp.Phase(0, 0, -1, -1, 3, 3, 0)
+    fn = _lib.lib().sg_conv2d_reduced
+    assert fn(ctypes.byref(p), _lib.ptr(x), None) == -2
+    assert b'exceed the fixed array' in _lib.lib().sg_last_error()
+    assert fn(ctypes.byref(p), None, None) == -3
+    p.reduce_out = _lib.ptr(x)
+    assert fn(ctypes.byref(p), _lib.ptr(x), None) == -1
