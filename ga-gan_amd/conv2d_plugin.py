@@ -26,7 +26,8 @@ class Conv2dParams(ctypes.Structure):
                 ('in_step', ctypes.c_int32), ('out_step', ctypes.c_int32), ('num_phases', ctypes.c_int32),
                 ('phase', Phase * 4),
                 ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
-                ('reduce_x', ctypes.c_void_p), ('reduce_out', ctypes.c_void_p)]
+                ('reduce_x', ctypes.c_void_p), ('reduce_out', ctypes.c_void_p),
+                ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float)]
 
 
 class Plan:
@@ -115,14 +116,18 @@ REDUCED_MAX_PARTIALS = 1 << 20   # SG_CONV2D_REDUCED_MAX_PARTIALS of include/sg_
 
 
 def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
-           act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None, reduce_x=None, out=None, reduce_sum=None):
+           act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None, reduce_x=None, out=None, reduce_sum=None,
+           mask_y=None, mask_alpha=1.0, mask_clamp=-1.0):
     """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow].
     `out_hw` overrides the plan's natural output size (pixels whose taps all fall outside x are zero).
     With `reduce_x` (y's shape and dtype) the call returns (y, r), r[n, co] = sum over pixels of
     reduce_x * (the contraction before out_scale and the epilogue), float32.
     With `out` (and, for a reduction, `reduce_sum` [n, co] float32) given, the results are written there and the
     call allocates no device memory: the reduction then runs through `sg_conv2d_reduced`, whose partial sums live
-    in a fixed array inside the library (at most REDUCED_MAX_PARTIALS of them, one call at a time per device)."""
+    in a fixed array inside the library (at most REDUCED_MAX_PARTIALS of them, one call at a time per device).
+    With `mask_y` (x's shape and dtype) x is contracted as x * m, m = 1 where mask_y > 0, else mask_alpha, and 0 where
+    |mask_y| >= mask_clamp (mask_clamp < 0: unbounded): the backward of a fused activation applied to the incoming
+    gradient while it is staged.  Ask `supports_mask` first."""
     if not x.is_cuda:
         raise RuntimeError('x must reside on CUDA device')
     if x.dim() != 4 or not x.is_contiguous():
@@ -162,12 +167,15 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
         return y if reduce_x is None else (y, reduce_sum if out is not None else torch.zeros([n, co], device=x.device))
     if reduce_x is not None and (reduce_x.shape != y.shape or reduce_x.dtype != x.dtype or not reduce_x.is_contiguous()):
         raise RuntimeError('reduce_x must be dense and match the output')
+    if mask_y is not None and (mask_y.shape != x.shape or mask_y.dtype != x.dtype or not mask_y.is_contiguous()):
+        raise RuntimeError('mask_y must be dense and match x')
     p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(w_packed), y=_lib.ptr(y), in_scale=_lib.ptr(in_scale),
                      out_scale=_lib.ptr(out_scale), bias=_lib.ptr(bias), noise=_lib.ptr(noise),
                      noise_gain=_lib.ptr(noise_gain), noise_stride_n=noise_stride, dtype=_lib.dtype_code(x),
                      n=n, ci=ci, h=h, w_in=w, co=co, oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step,
                      num_phases=len(plan.phases), act=ACT_INDEX[act], alpha=alpha, gain=gain, clamp=clamp,
-                     reduce_x=_lib.ptr(reduce_x), reduce_out=None)
+                     reduce_x=_lib.ptr(reduce_x), reduce_out=None, mask_y=_lib.ptr(mask_y), mask_alpha=mask_alpha,
+                     mask_clamp=mask_clamp)
     offset = 0
     for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
@@ -193,6 +201,26 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     if reduce_x is not None:
         return y, (partial.sum(dim=1) if partial.shape[1] > 1 else partial[:, 0])
     return y
+
+
+def supports_mask(x, plan, co, out_hw=None, reduce=False):
+    """True when `conv2d(x, ..., mask_y=...)` has a kernel for this geometry (x: the gradient tensor, co: channels of
+    the result)."""
+    if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in _DTYPE_NAME:
+        return False
+    n, ci, h, w = x.shape
+    oh, ow = plan.out_size(h, w) if out_hw is None else out_hw
+    p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(x), y=_lib.ptr(x), mask_y=_lib.ptr(x), dtype=_lib.dtype_code(x), n=n, ci=ci, h=h,
+                     w_in=w, co=co, oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step, num_phases=len(plan.phases),
+                     act=1, gain=1.0, clamp=-1.0, mask_clamp=-1.0)
+    if reduce:
+        p.reduce_x = _lib.ptr(x)
+        p.reduce_out = _lib.ptr(x)
+    offset = 0
+    for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
+        p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
+        offset += nky * nkx * co * ci
+    return bool(_lib.lib().sg_conv2d_supports_mask(ctypes.byref(p)))
 
 
 class Conv2dWgradParams(ctypes.Structure):

@@ -1076,6 +1076,8 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
                SG_ERR_INVALID_ARGUMENT, "conv2d: tensor is too large");
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->w && p->y, SG_ERR_NULL_POINTER, "conv2d: x, w and y must not be NULL");
+    if (band3x3_eligible(*p)) return band3x3_launch(*p, (hipStream_t)stream);
+    SG_REQUIRE(p->mask_y == nullptr, SG_ERR_UNSUPPORTED, "conv2d: no kernel applies an input mask for this geometry");
     if (conv3x3_eligible(*p)) return conv3x3_launch(*p, (hipStream_t)stream);
     if (conv_up2_eligible(*p)) return conv_up2_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
@@ -1110,14 +1112,23 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
 
 extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
     if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return -1;
+    if (sg::band3x3_eligible(*p)) return sg::band3x3_reduce_rows(*p);
     if (sg::conv3x3_eligible(*p)) return sg::conv3x3_reduce_rows(*p);
     int taps = 0;
     const sg::Tile t = sg::make_tile(*p, &taps);
     return (t.imgs == 1) ? t.tiles_a * t.tiles_b * p->num_phases : 1;
 }
 
+extern "C" int sg_conv2d_supports_mask(const sg_conv2d_params* p) {
+    if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return 0;
+    sg_conv2d_params q = *p;
+    if (q.mask_y == nullptr) q.mask_y = q.x;
+    return sg::band3x3_eligible(q) ? 1 : 0;
+}
+
 extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
     if (p == nullptr) return "";
+    if (sg::band3x3_eligible(*p)) return "band3x3_kernel";
     if (sg::conv_up2_eligible(*p)) return "conv_up2_kernel";
     if (!sg::conv3x3_eligible(*p)) return "conv2d_mfma_kernel";
     return sg::conv3x3_resident(*p) ? "conv3x3_resident_kernel" : "conv3x3_kernel";

@@ -26,6 +26,13 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
 bool conv3x3_resident(const sg_conv2d_params& p);       // eligible and narrow (<= 64 channels both sides): weights stay in LDS
 int conv3x3_reduce_rows(const sg_conv2d_params& p);   // partial rows per sample of the reduction, for eligible geometries
 
+int compute_units();   // of the current device
+
+// Same-size 3x3 convolution with 32 / 64 channels on both sides as persistent row bands (sg_band3x3.hip).
+bool band3x3_eligible(const sg_conv2d_params& p);
+int band3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
+int band3x3_reduce_rows(const sg_conv2d_params& p);
+
 // Transposed 3x3 stride-2 convolution as one unit-stride contraction over the 2 x 2 input window (sg_convup.hip).
 bool conv_up2_eligible(const sg_conv2d_params& p);
 int conv_up2_launch(const sg_conv2d_params& p, hipStream_t stream);

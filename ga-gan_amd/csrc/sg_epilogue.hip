@@ -3,12 +3,15 @@
 // the bias, of the per-sample scale (demodulation coefficients) and of the noise strength.  The
 // pre-activation value is recovered from the saved output (leaky ReLU is invertible; where the
 // output was clamped the gradient is zero and the value does not matter), so nothing but y is
-// kept from the forward pass.  One workgroup per (sample, channel) plane; HBM-bound: reads dy and
-// y once, writes dz once.
+// kept from the forward pass.  One workgroup per segment of kSegment elements of a (sample, channel)
+// plane; HBM-bound: reads dy and y once, writes dz once (or not at all: dz == NULL leaves only the
+// reductions, for callers whose convolution kernels apply the mask themselves).
 #include "sg_common.h"
 
 namespace sg {
 namespace {
+
+constexpr int kSegment = 16384;   // elements of a plane per workgroup
 
 template <class T>
 __global__ void __launch_bounds__(256) epilogue_bwd_kernel(sg_epilogue_bwd_params p) {
@@ -24,7 +27,8 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(sg_epilogue_bwd_param
     const float* __restrict__ nz = ep.noise ? ep.noise + (int64_t)n * ep.noise_stride_n : nullptr;
     const T* __restrict__ dy = (const T*)p.dy + (int64_t)plane * hw;
     const T* __restrict__ y = (const T*)p.y + (int64_t)plane * hw;
-    T* __restrict__ dz = (T*)p.dz + (int64_t)plane * hw;
+    T* __restrict__ dz = p.dz ? (T*)p.dz + (int64_t)plane * hw : nullptr;
+    const int seg0 = blockIdx.y * kSegment, seg1 = min(hw, seg0 + kSegment);
     const float inv_gain = (ep.gain != 0.f) ? 1.f / ep.gain : 0.f;
     const float inv_alpha = (ep.alpha != 0.f) ? 1.f / ep.alpha : 0.f;
     float sum_g = 0.f, sum_gv = 0.f, sum_gn = 0.f;
@@ -44,19 +48,21 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(sg_epilogue_bwd_param
         return g * scale;
     };
 
-    const bool vec = (hw % VEC == 0) && aligned16(p.dy) && aligned16(p.y) && aligned16(p.dz);
+    const bool vec = (hw % VEC == 0) && aligned16(p.dy) && aligned16(p.y) && aligned16(p.dz);   // kSegment is a multiple of VEC
     if (vec) {
-        for (int k = threadIdx.x; k < hw / VEC; k += blockDim.x) {
+        for (int k = seg0 / VEC + threadIdx.x; k < seg1 / VEC; k += blockDim.x) {
             const Pack<T> vy = load_pack(y + k * VEC), vd = load_pack(dy + k * VEC);
             Pack<T> out;
 #pragma unroll
             for (int j = 0; j < VEC; j++)
                 out.v[j] = Elem<T>::store(one((float)Elem<T>::load(vy.v[j]), (float)Elem<T>::load(vd.v[j]), k * VEC + j));
-            store_pack(dz + k * VEC, out);
+            if (dz) store_pack(dz + k * VEC, out);
         }
     } else {
-        for (int i = threadIdx.x; i < hw; i += blockDim.x)
-            dz[i] = Elem<T>::store(one((float)Elem<T>::load(y[i]), (float)Elem<T>::load(dy[i]), i));
+        for (int i = seg0 + threadIdx.x; i < seg1; i += blockDim.x) {
+            const T out = Elem<T>::store(one((float)Elem<T>::load(y[i]), (float)Elem<T>::load(dy[i]), i));
+            if (dz) dz[i] = out;
+        }
     }
 
     float sums[3] = {sum_g, sum_gv, sum_gn};
@@ -73,7 +79,7 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(sg_epilogue_bwd_param
         for (int q = 0; q < 3; q++)
             for (int wv = 0; wv < (int)(blockDim.x / kWave); wv++) tot[q] += scratch[q][wv];
         if (p.dbias) atomicAdd(p.dbias + c, tot[0]);
-        if (p.dscale) p.dscale[plane] = tot[1] / scale;
+        if (p.dscale) atomicAdd(p.dscale + plane, tot[1] / scale);
         if (p.dnoise_gain && nz) atomicAdd(p.dnoise_gain, tot[2]);
     }
 }
@@ -91,8 +97,8 @@ extern "C" int sg_epilogue_backward(const sg_epilogue_bwd_params* p, sg_stream_t
     SG_REQUIRE(!(p->dscale && p->ep.act == 3 && p->ep.alpha == 0.f), SG_ERR_UNSUPPORTED,
                "epilogue_backward: dscale with alpha = 0 (the activation is not invertible)");
     if (p->n == 0) return SG_OK;
-    SG_REQUIRE(p->dy && p->y && p->dz, SG_ERR_NULL_POINTER, "epilogue_backward: dy, y and dz must not be NULL");
-    dim3 grid((unsigned)(p->n * p->c));
+    SG_REQUIRE(p->dy && p->y, SG_ERR_NULL_POINTER, "epilogue_backward: dy and y must not be NULL");
+    dim3 grid((unsigned)(p->n * p->c), (unsigned)(((int64_t)p->h * p->w + kSegment - 1) / kSegment));
     switch (p->dtype) {
         case SG_F32: hipLaunchKernelGGL((epilogue_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, *p); break;
         case SG_F16: hipLaunchKernelGGL((epilogue_bwd_kernel<__half>), grid, dim3(256), 0, (hipStream_t)stream, *p); break;

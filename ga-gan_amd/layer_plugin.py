@@ -70,16 +70,16 @@ def blur_epilogue(x, f, padding, flip, filter_gain, **epilogue):
     return y
 
 
-def epilogue_backward(dy, y, want_dbias, want_dscale, want_dnoise_gain, **epilogue):
-    """-> (dz, dbias [c] | None, dscale [n, c] | None, dnoise_gain [] | None); all reductions float32."""
+def epilogue_backward(dy, y, want_dbias, want_dscale, want_dnoise_gain, want_dz=True, **epilogue):
+    """-> (dz | None, dbias [c] | None, dscale [n, c] | None, dnoise_gain [] | None); all reductions float32."""
     if not dy.is_cuda or dy.shape != y.shape or dy.dtype != y.dtype or y.dim() != 4:
         raise RuntimeError('dy and y must be GPU tensors of the same shape and dtype')
     dy, y = dy.contiguous(), y.contiguous()
     n, c, h, w = y.shape
     ep = make_epilogue(n, c, h, w, y.dtype, **epilogue)
-    dz = torch.empty_like(y)
+    dz = torch.empty_like(y) if want_dz else None
     dbias = torch.zeros([c], dtype=torch.float32, device=y.device) if want_dbias else None
-    dscale = torch.empty([n, c], dtype=torch.float32, device=y.device) if want_dscale else None
+    dscale = torch.zeros([n, c], dtype=torch.float32, device=y.device) if want_dscale else None
     dng = torch.zeros([], dtype=torch.float32, device=y.device) if want_dnoise_gain else None
     if y.numel():
         p = EpilogueBwdParams(dy=_lib.ptr(dy), y=_lib.ptr(y), dz=_lib.ptr(dz), ep=ep, dbias=_lib.ptr(dbias),

@@ -126,13 +126,31 @@ class _FusedConv(torch.autograd.Function):
 
         ep = dict(scale=dcoefs, noise=noise, noise_gain=noise_strength if noise is not None else None, bias=bias, act=act,
                   alpha=alpha, gain=gain, clamp=clamp)
-        dz, dbias, ddcoefs, dng = _layer.epilogue_backward(
-            dy, y if y is not None else dy, want_dbias=need[6] and bias is not None, want_dscale=need[3] and dcoefs is not None,
-            want_dnoise_gain=need[5] and noise is not None and noise_strength is not None, **ep)
+        want = dict(want_dbias=need[6] and bias is not None, want_dscale=need[3] and dcoefs is not None,
+                    want_dnoise_gain=need[5] and noise is not None and noise_strength is not None)
         dx = dw = dstyles = None
         ci = x.shape[1]
         want_ds = need[2] and styles is not None
         want_dx = need[0] or want_ds
+        dy = dy.contiguous()
+        # Data gradient with the activation mask applied to dy while the kernel stages it: no dz tensor.  Taken when
+        # nothing else needs dz (the weight gradient does) and a kernel exists for the geometry.
+        if mode == 'same' and want_dx and not need[1] and y is not None:
+            plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
+            if tuple(x.shape[2:]) == plan.out_size(*dy.shape[2:]) and _conv.supports_mask(dy, plan, ci, reduce=want_ds):
+                ddcoefs = dng = dbias = None
+                if any(want.values()):
+                    _, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y, want_dz=False, **want, **ep)
+                dx = _conv.conv2d(dy, plan.pack(w, transposed_layout=True), plan, ci, in_scale=dcoefs, out_scale=styles, gain=gain,
+                                  reduce_x=x if want_ds else None, mask_y=y, mask_alpha=alpha if act == 'lrelu' else 1.0,
+                                  mask_clamp=clamp)
+                if want_ds:
+                    dx, dstyles = dx
+                    dstyles = dstyles * gain      # the reduction is taken before the output scale and gain
+                return (dx if need[0] else None, None, dstyles, ddcoefs, None,
+                        dng.reshape(noise_strength.shape) if dng is not None else None,
+                        dbias.to(bias.dtype) if dbias is not None else None, None, None)
+        dz, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y if y is not None else dy, **want, **ep)
         if mode == 'same':
             if want_dx:
                 plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)

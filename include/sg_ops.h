@@ -98,8 +98,10 @@ int sg_upfirdn2d_epilogue(const sg_upfirdn2d_params* p, const sg_epilogue* ep, s
  *   g  = dy * gain * act'(.)  (zero where y was clamped; the activation's slope is taken from sign(y))
  *   dz = g * scale[n,c]                                   -> gradient w.r.t. the pre-epilogue value v
  *   dbias[c]      += sum_{n,hw} g                          (float atomics; caller zeroes)
- *   dscale[n,c]    = sum_hw g * v, with v recovered from y: v = (act^-1(y / gain) - noise * *noise_gain - bias[c]) / scale[n,c]
+ *   dscale[n,c]   += sum_hw g * v, with v recovered from y: v = (act^-1(y / gain) - noise * *noise_gain - bias[c]) / scale[n,c]
  *   dnoise_gain[0]+= sum g * noise
+ * (all three accumulated with float atomics: the caller zeroes them).  dz may be NULL: only the reductions are
+ * computed then, for callers that hand dy and y to sg_conv2d's input mask instead of materialising dz.
  * No counterpart in the reference's native code: it is the fusion of `bias_act`'s grad=1 kernel
  * (torch_utils/ops/bias_act.cu:132-142) with the reductions that `fma`'s and `bias_act`'s Python
  * backward run as separate tensor ops (torch_utils/ops/fma.py:36-45, bias_act.py:211-212). */
@@ -222,9 +224,20 @@ typedef struct sg_conv2d_params {
      * styles in the same pass. */
     const void* reduce_x;
     float* reduce_out;
+    /* optional input mask, for the call that computes the data gradient of a layer whose epilogue was fused: x is the
+     * gradient dy that arrived at the layer's output and mask_y the output the forward pass saved (x's shape and
+     * dtype).  The kernel then contracts x * m, m = (mask_y > 0 ? 1 : mask_alpha), m = 0 where |mask_y| >= mask_clamp
+     * (mask_clamp < 0: no bound): `bias_act`'s first-order backward (torch_utils/ops/bias_act.cu:132-142, without its
+     * gain, which the caller folds into `gain`) applied while the operand is staged.  NULL = no mask.  Only some
+     * kernels implement it: ask sg_conv2d_supports_mask() first; an unsupported call returns SG_ERR_UNSUPPORTED. */
+    const void* mask_y;
+    float mask_alpha, mask_clamp;
 } sg_conv2d_params;
 
 int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
+
+/* 1 when sg_conv2d honours p->mask_y for this geometry (decided as if mask_y were set), else 0. */
+int sg_conv2d_supports_mask(const sg_conv2d_params* p);
 
 /* Number of partial rows per sample the reduction above writes for this geometry (>= 1), -1 on a bad argument. */
 int sg_conv2d_reduce_rows(const sg_conv2d_params* p);
@@ -243,7 +256,8 @@ int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t 
 /* Name of the device kernel sg_conv2d runs for this geometry (the symbol a profiler reports, without template
  * arguments).  For 16-bit tensors whose rows are whole aligned packets: "conv3x3_kernel" (3x3, output step 1,
  * input step 1 or 2), "conv3x3_resident_kernel" (the same with at most 64 channels on both sides: the weights
- * stay in LDS), "conv_up2_kernel" (3x3 transposed, stride 2, no epilogue); "conv2d_mfma_kernel" otherwise.
+ * stay in LDS), "conv_up2_kernel" (3x3 transposed, stride 2, no epilogue), "band3x3_kernel" (3x3 same-size, 32 or 64
+ * channels on both sides: persistent row bands with the weights in registers); "conv2d_mfma_kernel" otherwise.
  * Static storage. */
 const char* sg_conv2d_kernel(const sg_conv2d_params* p);
 
