@@ -21,6 +21,9 @@ OUT = os.path.join(HERE, 'libsgops.so')
 OBJ_DIR = os.path.join(HERE, 'build')
 CFLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
           '-Wno-unused-const-variable']
+# per-source additions.  The band kernel's epilogue runs beside matrix instructions, where packed float32 vector
+# instructions (what the SLP vectoriser makes of adjacent scalar multiplies) cost more than the two scalar ones.
+EXTRA_CFLAGS = {'sg_band3x3': ['-fno-slp-vectorize']}
 
 
 def sources():
@@ -54,7 +57,8 @@ def _plan():
     items = []
     for src in sources():
         stem = os.path.splitext(os.path.basename(src))[0]
-        items.append((src, os.path.join(OBJ_DIR, stem + '.o'), os.path.join(OBJ_DIR, stem + '.md5'), _digest([src], common)))
+        items.append((src, os.path.join(OBJ_DIR, stem + '.o'), os.path.join(OBJ_DIR, stem + '.md5'),
+                      _digest([src], common + ' '.join(EXTRA_CFLAGS.get(stem, [])))))
     return items, hashlib.md5(''.join(i[3] for i in items).encode()).hexdigest()
 
 
@@ -79,7 +83,8 @@ def build(force=False, verbose=True, jobs=None):
 
             def compile_one(item):
                 src, obj, stamp, digest = item
-                cmd = [hipcc, *CFLAGS, *include, '-c', src, '-o', obj]
+                stem = os.path.splitext(os.path.basename(src))[0]
+                cmd = [hipcc, *CFLAGS, *EXTRA_CFLAGS.get(stem, []), *include, '-c', src, '-o', obj]
                 if verbose:
                     print(' '.join(cmd), flush=True)
                 subprocess.run(cmd, check=True)

@@ -1,29 +1,35 @@
-// 3x3, unit-stride, same-size convolution of 16-bit tensors with 32 or 64 channels on either side: the layers at
-// 256^2 ... 1024^2, whose arithmetic intensity (144 - 288 flop/B) puts them at the HBM roofline once the contraction
-// runs on the matrix cores.  The design goal is therefore "every input byte is fetched from memory once, every output
-// byte stored once, and nothing else stands in the way":
+// 3x3, unit-stride, same-size convolution of 16-bit tensors with 32 input channels and 32 or 64 output channels: the
+// layers at 1024^2 (and the 32 -> 64 layers at 512^2), whose arithmetic intensity (144 flop/B) puts them at the HBM
+// roofline once the contraction runs on the matrix cores.  The design goal is therefore "every input byte is fetched
+// from memory once, every output byte stored once, and the memory system is never left idle":
 //
-//   * A persistent workgroup of 8 waves owns a BAND of 8 output rows of one sample and 32 output channels, and walks
+//   * A persistent workgroup of 8 waves owns a BAND of 6 output rows of one sample and 32 output channels, and walks
 //     it from left to right in steps of 64 pixels.  The 9 right-most input columns of a step stay in LDS for the next
-//     one, so each step loads exactly the 64 new columns (whole 128-byte lines), never a halo column.  Outputs lag
-//     the loads by 8 columns (step t produces columns 64 t - 8 .. 64 t + 55), which keeps the stores 16-byte aligned.
+//     one, so each step loads exactly the 64 new columns, never a halo column.  Outputs lag the loads by 8 columns
+//     (step t produces columns 64 t - 8 .. 64 t + 55), which keeps the stores 16-byte aligned.
 //   * The weights of the workgroup's channels (with the per-sample modulation folded in: w * s[n, ci]) live in
-//     REGISTERS as matrix-instruction fragments for the whole band (72 registers per 32 input channels): the multiply
-//     phase reads nothing but pixels from LDS, one 16-byte read per three matrix instructions.
-//   * NCHW rows are transposed to the [pixel][channel] image the matrix instruction wants with one byte-permute per
-//     two elements (4 channels x 8 pixels per lane) and 8-byte LDS stores that are bank-conflict free.
-//   * Loads for the next phase are issued before the current phase's multiplies and committed after them; the image
-//     buffers rotate, so one barrier per phase suffices.
+//     REGISTERS as matrix-instruction fragments for the whole band (72 registers): the multiply phase reads nothing
+//     but pixels from LDS, one 16-byte read per 1.5 matrix instructions.
+//   * A step's image is 8 rows x 64 pixels x 32 channels = 512 staging units of 4 channels x 8 pixels: one per lane.
+//     The unit's four 16-byte packets are loaded TWO steps ahead into one of two register sets (the loads of a step
+//     have two steps' time to arrive, and memory requests are in flight all the time), transposed to the
+//     [pixel][channel] image with one byte-permute per two elements and written with conflict-free 8-byte LDS stores.
+//   * The image buffers alternate, so one barrier per step suffices.  Waves 4..7 run their epilogue half a step late
+//     (after the barrier, before their next multiplies): on every SIMD one wave multiplies while its partner does
+//     vector arithmetic and stores, instead of both queueing for the matrix pipe and then both for the vector pipe.
 //   * v_mfma_f32_32x32x16: 32 pixels x 32 channels per instruction; the pixel rows are permuted so that a lane ends up
-//     with 16 consecutive pixels of one channel (two 16-byte stores), no transposition on the way out.
+//     with 16 consecutive pixels of one channel; results leave through a wave-private LDS tile so that four lanes
+//     store one 64-byte run.
 //   * As the data gradient of such a layer the kernel applies the activation mask of the layer's saved output while it
-//     stages the incoming gradient (mask_y): no separate pass, no intermediate tensor.
+//     stages the incoming gradient (mask_y): no separate pass, no intermediate tensor.  (Two tensors per unit: the
+//     loads then run one step ahead only.)
 //
-// GEMM view: M = pixels, N = 32 output channels, K = input channels x 9 taps.  sg_conv2d dispatches here.
+// GEMM view: M = pixels, N = 32 output channels, K = 32 input channels x 9 taps.  sg_conv2d dispatches here.
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace sg {
 namespace {
@@ -52,15 +58,17 @@ __device__ __forceinline__ void store16(rsrc_t r, unsigned voff, const uint4& v)
 }
 
 constexpr int kThreads = 512;
+constexpr int R = 6;                     // output rows of a band
+constexpr int IH = R + 2;                // image rows: row r holds input row y0 - 1 + r
 constexpr int TWX = 64;                  // new input columns per step
 constexpr int CARRY = 9;                 // columns kept from the previous step
 constexpr int IW = TWX + CARRY;          // image columns: column i holds input column 64 t - 9 + i (odd: see img_off)
 constexpr int kPix = 64;                 // bytes per pixel: 32 channels
-// A band has R = 8 output rows (10 image rows: 640 staging units of 4 channels x 8 pixels, lanes 0..127 take two) or,
-// where registers are short (masked input: a lane holds the packets of two tensors; reduction operand), R = 6 (8 image
-// rows: one unit per lane).
-constexpr int band_rows(bool lean) { return lean ? 6 : 8; }
-constexpr int kNoise = 8 * TWX * 4;      // noise tile of a step, float32
+constexpr int kImg = IH * IW * kPix;     // 37376 bytes per image
+constexpr int kNoise = R * TWX;          // floats of a step's noise tile
+constexpr int kOutRow = 80;              // a wave's results pass through LDS as runs of 32 pixels (64 bytes) + 16 bytes of padding
+constexpr int kOutWave = 2 * 32 * kOutRow;
+constexpr size_t kLds = 2 * kImg + 3 * kNoise * sizeof(float) + 8 * 32 * sizeof(float) + 8 * kOutWave;
 
 template <class T> struct Mma32;
 template <> struct Mma32<__hip_bfloat16> {
@@ -112,18 +120,32 @@ struct BandArgs {
 // the 128-byte window of an 8-byte store: the 16 lanes of a store group (8 channel groups x 2 rows) never collide.
 __device__ __forceinline__ int img_off(int r, int c, int s) { return (r * IW + c) * kPix + (((s ^ (c >> 2)) & 3) << 4); }
 
-template <class T, int KC, bool MASK, bool REDUCE>
-__global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
-    constexpr int NBUF = KC + 1;
-    constexpr int R = band_rows(MASK || REDUCE), IH = R + 2, kImg = IH * IW * kPix;
-    constexpr bool TWO_UNITS = IH > 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* s_img = smem;                                       // [NBUF][kImg]
-    float* s_noise = reinterpret_cast<float*>(smem + NBUF * kImg);     // [2][8][TWX]
-    float* s_red = s_noise + 2 * 8 * TWX;                              // [8 waves][32]
+#ifdef BAND_ABL_STAMPS
+__device__ unsigned long long band_stamps[8][8][8];   // [wave][step 4..11][point]
+#define STAMP(q, k) do { if (blockIdx.x == 0 && item == (int)(blockIdx.x >> 3) && (q) >= 4 && (q) < 12 && lane == 0) band_stamps[wave][(q) - 4][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(q, k) do {} while (0)
+#endif
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sx = wave & 1, rg = wave >> 1;          // strip of 32 output columns, output rows 2 rg and 2 rg + 1
+template <bool MASK> struct Staged {   // the packets of one staging unit (and of its mask), and a piece of the noise tile
+    uint4 p[4];
+    uint4 m[MASK ? 4 : 1];
+    float4 pn;
+};
+
+template <class T, bool MASK, bool REDUCE>
+__global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
+    constexpr int DEPTH = (MASK || REDUCE) ? 1 : 2;   // steps between the loads of an image and their use (registers decide)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_img = smem;                                       // [2][kImg]
+    float* s_noise = reinterpret_cast<float*>(smem + 2 * kImg);        // [3][R][TWX]
+    float* s_red = s_noise + 3 * kNoise;                               // [8 waves][32]
+    unsigned char* s_out = reinterpret_cast<unsigned char*>(s_red + 8 * 32) + (threadIdx.x >> 6) * kOutWave;   // this wave's [2][32][kOutRow]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sx = wave & 1, rg = wave >> 1;          // strip of 32 output columns, output rows 2 rg and 2 rg + 1 (rg = 3: none)
+    const bool late = !MASK && wave >= 4;            // these waves finish a step's results after the step's barrier
     const int lc = lane & 31, hh = lane >> 5;         // matrix row / column index, half
     // matrix row rho of the pixel operand holds strip pixel 16 h' + 4 q + j (rho = 8 q + 4 h' + j), so that the 16
     // accumulator registers of a lane are 16 consecutive pixels
@@ -131,18 +153,15 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
     const int c0px = 32 * sx + pi;                    // image column of this lane's pixel for the left tap
 
     const int NT = (g.wid + TWX - 1) / TWX;           // loading steps; step NT only finishes the last 8 columns
-    const int Q = (NT + 1) * KC;
+    const int Q = NT + 1;
     const int64_t plane = (int64_t)g.h * g.wid;
     const unsigned uplane = (unsigned)plane;
     const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
 
-    // staging unit u: 4 channels c4, image row r, packet v of 8 pixels.  Consecutive lanes take the 8 channel groups
-    // of one pixel (64 contiguous bytes in LDS) and then the next image row (an odd number of pixels further): 16
-    // lanes fill all 32 banks once.
-    const int u_c4 = tid & 7, u_v = (tid >> 4) & 7;
-    const int u_rA = 2 * (tid >> 7) + ((tid >> 3) & 1);     // rows 0..7
-    const int u_rB = 8 + ((tid >> 3) & 1);                  // rows 8, 9: lanes 0..127 only
-    const bool has_B = TWO_UNITS && tid < 128;
+    // staging unit of this lane: 4 channels u_c4, image row u_r, packet u_v of 8 pixels.  Consecutive lanes take the 8
+    // channel groups of one pixel (64 contiguous bytes in LDS) and then the next image row (an odd number of pixels
+    // further): 16 lanes fill all 32 banks once.
+    const int u_c4 = tid & 7, u_v = (tid >> 4) & 7, u_r = 2 * (tid >> 7) + ((tid >> 3) & 1);
 
     const int xcd = blockIdx.x & 7, per_xcd = (g.items + 7) >> 3, stride = gridDim.x >> 3;
     const int item_end = min(g.items, (xcd + 1) * per_xcd);
@@ -158,78 +177,67 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
         const rsrc_t rr = make_rsrc(REDUCE ? (const T*)g.reduce_x + (int64_t)n * g.co * plane : (const T*)g.x, REDUCE ? out_bytes : 0u);
         const rsrc_t yr = make_rsrc((T*)g.y + (int64_t)n * g.co * plane, out_bytes);
 
-        // ---- weights of this sample and channel group -> registers: fragment (kc, tap, ks) holds input channels
-        // 32 kc + 16 ks + 8 hh .. + 7 of output channel cout ---------------------------------------------------------
-        uint4 wreg[KC][9][2];
+        // ---- weights of this sample and channel group -> registers: fragment (tap, ks) holds input channels
+        // 16 ks + 8 hh .. + 7 of output channel cout ----------------------------------------------------------------
+        uint4 wreg[9][2];
         {
             const T* __restrict__ wsrc = (const T*)g.w;
 #pragma unroll
-            for (int kc = 0; kc < KC; kc++)
+            for (int ks = 0; ks < 2; ks++) {
+                const int c0 = 16 * ks + 8 * hh;
+                float s[8];
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++) {
-                    const int c0 = 32 * kc + 16 * ks + 8 * hh;
-                    float s[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) s[j] = 1.f;
-                    if (g.in_scale) {
-                        const float4 a = *reinterpret_cast<const float4*>(g.in_scale + (int64_t)n * g.ci + c0);
-                        const float4 b = *reinterpret_cast<const float4*>(g.in_scale + (int64_t)n * g.ci + c0 + 4);
-                        s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-                    }
-#pragma unroll
-                    for (int tap = 0; tap < 9; tap++) {
-                        uint4 v = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)tap * g.co + cout) * g.ci + c0);
-                        if (g.in_scale) {
-                            v.x = Pair<T>::pack(Pair<T>::lo(v.x) * s[0], Pair<T>::hi(v.x) * s[1]);
-                            v.y = Pair<T>::pack(Pair<T>::lo(v.y) * s[2], Pair<T>::hi(v.y) * s[3]);
-                            v.z = Pair<T>::pack(Pair<T>::lo(v.z) * s[4], Pair<T>::hi(v.z) * s[5]);
-                            v.w = Pair<T>::pack(Pair<T>::lo(v.w) * s[6], Pair<T>::hi(v.w) * s[7]);
-                        }
-                        wreg[kc][tap][ks] = v;
-                    }
+                for (int j = 0; j < 8; j++) s[j] = 1.f;
+                if (g.in_scale) {
+                    const float4 a = *reinterpret_cast<const float4*>(g.in_scale + (int64_t)n * g.ci + c0);
+                    const float4 b = *reinterpret_cast<const float4*>(g.in_scale + (int64_t)n * g.ci + c0 + 4);
+                    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
                 }
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    uint4 v = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)tap * g.co + cout) * g.ci + c0);
+                    if (g.in_scale) {
+                        v.x = Pair<T>::pack(Pair<T>::lo(v.x) * s[0], Pair<T>::hi(v.x) * s[1]);
+                        v.y = Pair<T>::pack(Pair<T>::lo(v.y) * s[2], Pair<T>::hi(v.y) * s[3]);
+                        v.z = Pair<T>::pack(Pair<T>::lo(v.z) * s[4], Pair<T>::hi(v.z) * s[5]);
+                        v.w = Pair<T>::pack(Pair<T>::lo(v.w) * s[6], Pair<T>::hi(v.w) * s[7]);
+                    }
+                    wreg[tap][ks] = v;
+                }
+            }
         }
-        const float sc = g.out_scale ? g.out_scale[(int64_t)n * g.co + cout] : 1.f;
-        const float bs = g.bias ? Pair<T>::lo((unsigned)__builtin_bit_cast(unsigned short, ((const T*)g.bias)[cout])) : 0.f;
+        // epilogue constants with the (positive) gain folded in: clamp(lrelu(v sc + noise ng + b) gain) =
+        // clamp(lrelu(v (sc gain) + noise (ng gain) + b gain)), and lrelu(z) = max(z, slope z) for 0 <= slope <= 1
+        const float scg = (g.out_scale ? g.out_scale[(int64_t)n * g.co + cout] : 1.f) * g.gain;
+        const float bsg = (g.bias ? Pair<T>::lo((unsigned)__builtin_bit_cast(unsigned short, ((const T*)g.bias)[cout])) : 0.f) * g.gain;
+        const float ngg = noise_gain * g.gain;
 
-        // ---- left border: the carried columns of the first step's images are zero --------------------------------
-        for (int e = tid; e < KC * IH * CARRY * 4; e += kThreads) {
-            const int s = e & 3, c = (e >> 2) % CARRY, r = ((e >> 2) / CARRY) % IH, b = (e >> 2) / (CARRY * IH);
-            *reinterpret_cast<uint4*>(s_img + b * kImg + img_off(r, c, s)) = make_uint4(0, 0, 0, 0);
+        // ---- left border: the carried columns of the first step's image are zero ----------------------------------
+        if (tid < IH * CARRY * 4) {
+            const int s = tid & 3, c = (tid >> 2) % CARRY, r = (tid >> 2) / CARRY;
+            *reinterpret_cast<uint4*>(s_img + img_off(r, c, s)) = make_uint4(0, 0, 0, 0);
         }
 
-        // ---- staging: loads of a phase into registers, later masked / transposed / written to LDS -----------------
-        uint4 pa[4], pb[TWO_UNITS ? 4 : 1], ma[MASK ? 4 : 1], mb[MASK && TWO_UNITS ? 4 : 1];
-        float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto issue = [&](int q) {
-            const int t = q / KC, kc = q - t * KC;
-            const int col = t * TWX + 8 * u_v;
-            const bool col_ok = t < NT && col < g.wid;
-            const int ya = y0 - 1 + u_rA, yb = y0 - 1 + u_rB;
-            const bool ok_a = col_ok && ya >= 0 && ya < g.h, ok_b = has_B && col_ok && yb >= 0 && yb < g.h;
-            const unsigned base = ((unsigned)(32 * kc + 4 * u_c4) * uplane + (unsigned)(ya * g.wid + col)) * 2u;   // bytes
-            const unsigned off_a = ok_a ? base : kOutside;
-            const unsigned off_b = ok_b ? base + (unsigned)((u_rB - u_rA) * g.wid) * 2u : kOutside;
+        // ---- staging: loads of a step into registers, later masked / transposed / written to LDS -------------------
+        auto issue = [&](int q, Staged<MASK>& st) {
+            const int col = q * TWX + 8 * u_v, yy = y0 - 1 + u_r;
+            const bool ok = q < NT && col < g.wid && yy >= 0 && yy < g.h;
+            const unsigned off = ok ? ((unsigned)(4 * u_c4) * uplane + (unsigned)(yy * g.wid + col)) * 2u : kOutside;   // bytes
 #pragma unroll
             for (int e = 0; e < 4; e++) {
 #ifdef BAND_ABL_NOLOAD
-                pa[e] = make_uint4(q, e, tid, 1);
-                if constexpr (TWO_UNITS) pb[e] = make_uint4(q, e, tid, 2);
+                st.p[e] = make_uint4(q, e, tid, 1);
                 continue;
 #endif
-                pa[e] = load16(xr, off_a, e * uplane * 2u);
-                if constexpr (TWO_UNITS) pb[e] = load16(xr, off_b, e * uplane * 2u);
-                if constexpr (MASK) {
-                    ma[e] = load16(mr, off_a, e * uplane * 2u);
-                    if constexpr (TWO_UNITS) mb[e] = load16(mr, off_b, e * uplane * 2u);
-                }
+                st.p[e] = load16(xr, off, e * uplane * 2u);
+                if constexpr (MASK) st.m[e] = load16(mr, off, e * uplane * 2u);
             }
-            // noise tile of the step this phase opens (output columns 64 t - 8 ..): lanes 384..511, one float4 each
-            if (g.noise && kc == 0 && tid >= 384) {
-                const int id = tid - 384, row = y0 + (id >> 4), c = t * TWX - 8 + 4 * (id & 15);
-                pn = make_float4(0.f, 0.f, 0.f, 0.f);
+            // noise tile of the step (output columns 64 q - 8 ..): lanes 384..511, one float4 each
+            if (g.noise && tid >= 384) {
+                const int id = tid - 384, row = y0 + (id >> 4), c = q * TWX - 8 + 4 * (id & 15);
+                st.pn = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((id >> 4) < R && row < g.h && c >= 0 && c < g.wid)
-                    pn = *reinterpret_cast<const float4*>(g.noise + (int64_t)n * g.noise_stride + (int64_t)row * g.wid + c);
+                    st.pn = *reinterpret_cast<const float4*>(g.noise + (int64_t)n * g.noise_stride + (int64_t)row * g.wid + c);
             }
         };
         auto masked = [&](unsigned d, unsigned m) -> unsigned {   // two gradient elements times the mask of two saved outputs
@@ -239,14 +247,15 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
             fh = (fabsf(mh) < g.m_hi) ? fh : 0.f;
             return Pair<T>::pack(Pair<T>::lo(d) * fl, Pair<T>::hi(d) * fh);
         };
-        auto commit_unit = [&](unsigned char* img, int r, auto& p, auto& m) {
+        auto commit = [&](int q, Staged<MASK>& st) {
+            unsigned char* img = s_img + (q & 1) * kImg;
             unsigned wd[4][4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                wd[e][0] = p[e].x; wd[e][1] = p[e].y; wd[e][2] = p[e].z; wd[e][3] = p[e].w;
+                wd[e][0] = st.p[e].x; wd[e][1] = st.p[e].y; wd[e][2] = st.p[e].z; wd[e][3] = st.p[e].w;
                 if constexpr (MASK) {
-                    wd[e][0] = masked(wd[e][0], m[e].x); wd[e][1] = masked(wd[e][1], m[e].y);
-                    wd[e][2] = masked(wd[e][2], m[e].z); wd[e][3] = masked(wd[e][3], m[e].w);
+                    wd[e][0] = masked(wd[e][0], st.m[e].x); wd[e][1] = masked(wd[e][1], st.m[e].y);
+                    wd[e][2] = masked(wd[e][2], st.m[e].z); wd[e][3] = masked(wd[e][3], st.m[e].w);
                 }
             }
 #pragma unroll
@@ -258,41 +267,24 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
 #ifdef BAND_ABL_NOCOMMIT
                 asm volatile("" :: "v"(o.x), "v"(o.y));
 #else
-                *reinterpret_cast<uint2*>(img + img_off(r, CARRY + 8 * u_v + j, u_c4 >> 1) + 8 * (u_c4 & 1)) = o;
+                *reinterpret_cast<uint2*>(img + img_off(u_r, CARRY + 8 * u_v + j, u_c4 >> 1) + 8 * (u_c4 & 1)) = o;
 #endif
             }
-        };
-        auto commit = [&](int q) {
-            const int t = q / KC, kc = q - t * KC;
-            unsigned char* img = s_img + (q % NBUF) * kImg;
-            commit_unit(img, u_rA, pa, ma);
-            if constexpr (TWO_UNITS) {
-                if (has_B) commit_unit(img, u_rB, pb, mb);
+            if (q >= 1 && tid < IH * CARRY * 4) {   // the 9 right-most columns of the previous image
+                const unsigned char* prev = s_img + ((q - 1) & 1) * kImg;
+                const int s = tid & 3, c = (tid >> 2) % CARRY, r = (tid >> 2) / CARRY;
+                *reinterpret_cast<uint4*>(img + img_off(r, c, s)) = *reinterpret_cast<const uint4*>(prev + img_off(r, TWX + c, s));
             }
-            if (q >= KC) {   // the 9 right-most columns of the same chunk's previous image
-                const unsigned char* prev = s_img + ((q - KC) % NBUF) * kImg;
-                if (tid < IH * CARRY * 4) {
-                    const int s = tid & 3, c = (tid >> 2) % CARRY, r = (tid >> 2) / CARRY;
-                    *reinterpret_cast<uint4*>(img + img_off(r, c, s)) = *reinterpret_cast<const uint4*>(prev + img_off(r, TWX + c, s));
-                }
-            }
-            if (g.noise && kc == 0 && tid >= 384)
-                *reinterpret_cast<float4*>(s_noise + (t & 1) * 8 * TWX + (tid - 384) * 4) = pn;
+            if (g.noise && tid >= 384) *reinterpret_cast<float4*>(s_noise + (q % 3) * kNoise + (tid - 384) * 4) = st.pn;
         };
 
-        float red = 0.f;
-        __syncthreads();          // the previous item's last reads are done; the zeroed columns are in place
-        issue(0);
-        commit(0);
-        __syncthreads();
-
+        // ---- a step's arithmetic ------------------------------------------------------------------------------------
         f32x16_t acc[2];
-        for (int q = 0; q < Q; q++) {
-            const int t = q / KC, kc = q - t * KC;
-            if (q + 1 < Q) issue(q + 1);
-            const bool active = (t < NT || sx == 0) && 2 * rg < R;   // the closing step only has the 8 left-most columns left
-            uint4 rx[REDUCE ? 2 : 1][2];
-            if (REDUCE && kc == KC - 1 && active) {
+        uint4 rx[REDUCE ? 2 : 1][2];
+        float red = 0.f;
+        auto active = [&](int t) { return (t < NT || sx == 0) && rg < 3; };   // the closing step only has the 8 left-most columns left
+        auto load_rx = [&](int t) {
+            if constexpr (REDUCE) {
 #pragma unroll
                 for (int o = 0; o < 2; o++)
 #pragma unroll
@@ -302,93 +294,124 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
                         rx[o][gq] = load16(rr, ok ? ((unsigned)cout * uplane + (unsigned)(row * g.wid + col0)) * 2u : kOutside, 0);
                     }
             }
-            if (active) {
-                if (kc == 0) {
+        };
+        auto multiply = [&](int t) {
 #pragma unroll
-                    for (int o = 0; o < 2; o++)
+            for (int o = 0; o < 2; o++)
 #pragma unroll
-                        for (int e = 0; e < 16; e++) acc[o][e] = 0.f;
-                }
-                const unsigned char* img = s_img + (q % NBUF) * kImg;
+                for (int e = 0; e < 16; e++) acc[o][e] = 0.f;
+            const unsigned char* img = s_img + (t & 1) * kImg;
+            // 12 (input row, column shift) pairs; the fragments of pair i + 1 are read while pair i multiplies
+            uint4 fa[2][2];
+            auto read_pair = [&](int idx, uint4 (&f)[2]) {
+                const int r = 2 * rg + idx / 3, c = c0px + idx % 3;
+                f[0] = *reinterpret_cast<const uint4*>(img + img_off(r, c, hh));
+                f[1] = *reinterpret_cast<const uint4*>(img + img_off(r, c, 2 + hh));
+            };
+            read_pair(0, fa[0]);
 #pragma unroll
-                for (int kcc = 0; kcc < KC; kcc++) {
-                    if (kcc != kc) continue;     // static register indices: the chunk loop is unrolled
-                    // 12 (input row, column shift) pairs; the fragments of pair i + 1 are read while pair i multiplies
-                    uint4 fa[2][2];
-                    auto read_pair = [&](int idx, uint4 (&f)[2]) {
-                        const int r = 2 * rg + idx / 3, c = c0px + idx % 3;
-                        f[0] = *reinterpret_cast<const uint4*>(img + img_off(r, c, hh));
-                        f[1] = *reinterpret_cast<const uint4*>(img + img_off(r, c, 2 + hh));
-                    };
-                    read_pair(0, fa[0]);
+            for (int idx = 0; idx < 12; idx++) {
+                if (idx + 1 < 12) read_pair(idx + 1, fa[(idx + 1) & 1]);
+                const int ir = idx / 3, kx = idx % 3;
 #pragma unroll
-                    for (int idx = 0; idx < 12; idx++) {
-                        if (idx + 1 < 12) read_pair(idx + 1, fa[(idx + 1) & 1]);
-                        const int ir = idx / 3, kx = idx % 3;
+                for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-                        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                            for (int ky = 0; ky < 3; ky++) {
-                                const int o = ir - ky;
+                    for (int ky = 0; ky < 3; ky++) {
+                        const int o = ir - ky;
 #ifdef BAND_ABL_NOMFMA
-                                if (o == 0 || o == 1) { acc[o][0] += __builtin_bit_cast(float, fa[idx & 1][ks].x ^ wreg[kcc][ky * 3 + kx][ks].y); }
+                        if (o == 0 || o == 1) { acc[o][0] += __builtin_bit_cast(float, fa[idx & 1][ks].x ^ wreg[ky * 3 + kx][ks].y); }
 #else
-                                if (o == 0 || o == 1) Mma32<T>::run(fa[idx & 1][ks], wreg[kcc][ky * 3 + kx][ks], acc[o]);
+                        if (o == 0 || o == 1) Mma32<T>::run(fa[idx & 1][ks], wreg[ky * 3 + kx][ks], acc[o]);
 #endif
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-
-                // ---- epilogue of the step: after its last chunk ---------------------------------------------------
-                if (kc == KC - 1) {
-                    const float* nz = s_noise + (t & 1) * 8 * TWX;
-#pragma unroll
-                    for (int o = 0; o < 2; o++) {
-                        const int row = y0 + 2 * rg + o;
-#pragma unroll
-                        for (int gq = 0; gq < 2; gq++) {
-                            const int col0 = t * TWX - 8 + 32 * sx + 16 * hh + 8 * gq;
-                            const bool ok = row < g.h && col0 >= 0 && col0 < g.wid;   // rx is zero otherwise
-                            float v[8];
-#pragma unroll
-                            for (int e = 0; e < 8; e++) v[e] = acc[o][8 * gq + e];
-                            if constexpr (REDUCE) {
-                                const unsigned wr[4] = {rx[o][gq].x, rx[o][gq].y, rx[o][gq].z, rx[o][gq].w};
-#pragma unroll
-                                for (int e = 0; e < 4; e++) red += v[2 * e] * Pair<T>::lo(wr[e]) + v[2 * e + 1] * Pair<T>::hi(wr[e]);
-                            }
-                            float nzv[8];
-#pragma unroll
-                            for (int e = 0; e < 8; e++) nzv[e] = 0.f;
-                            if (g.noise) {
-                                const float4 a = *reinterpret_cast<const float4*>(nz + (2 * rg + o) * TWX + 32 * sx + 16 * hh + 8 * gq);
-                                const float4 b = *reinterpret_cast<const float4*>(nz + (2 * rg + o) * TWX + 32 * sx + 16 * hh + 8 * gq + 4);
-                                nzv[0] = a.x; nzv[1] = a.y; nzv[2] = a.z; nzv[3] = a.w; nzv[4] = b.x; nzv[5] = b.y; nzv[6] = b.z; nzv[7] = b.w;
-                            }
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-#ifdef BAND_ABL_NOEPI
-                                continue;
-#endif
-                                float z = v[e] * sc + nzv[e] * noise_gain + bs;
-                                z = (z > 0.f) ? z : z * g.slope;
-                                v[e] = fminf(fmaxf(z * g.gain, -g.hi), g.hi);
-                            }
-                            const uint4 out = make_uint4(Pair<T>::pack(v[0], v[1]), Pair<T>::pack(v[2], v[3]),
-                                                         Pair<T>::pack(v[4], v[5]), Pair<T>::pack(v[6], v[7]));
-#ifdef BAND_ABL_NOSTORE
-                            asm volatile("" :: "v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
-#else
-                            store16(yr, ok ? ((unsigned)cout * uplane + (unsigned)(row * g.wid + col0)) * 2u : kOutside, out);
-#endif
-                        }
-                    }
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (q + 1 < Q) commit(q + 1);
+        };
+        auto epilogue = [&](int t) {
+            const float* nz = s_noise + (t % 3) * kNoise;
+#pragma unroll
+            for (int o = 0; o < 2; o++)
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = acc[o][8 * gq + e];
+                    if constexpr (REDUCE) {   // rx is zero outside the image
+                        const unsigned wr[4] = {rx[o][gq].x, rx[o][gq].y, rx[o][gq].z, rx[o][gq].w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) red += v[2 * e] * Pair<T>::lo(wr[e]) + v[2 * e + 1] * Pair<T>::hi(wr[e]);
+                    }
+                    float nzv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) nzv[e] = 0.f;
+                    if (g.noise) {
+                        const float4 a = *reinterpret_cast<const float4*>(nz + (2 * rg + o) * TWX + 32 * sx + 16 * hh + 8 * gq);
+                        const float4 b = *reinterpret_cast<const float4*>(nz + (2 * rg + o) * TWX + 32 * sx + 16 * hh + 8 * gq + 4);
+                        nzv[0] = a.x; nzv[1] = a.y; nzv[2] = a.z; nzv[3] = a.w; nzv[4] = b.x; nzv[5] = b.y; nzv[6] = b.z; nzv[7] = b.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+#ifdef BAND_ABL_NOEPI
+                        continue;
+#endif
+                        float z = __builtin_fmaf(v[e], scg, __builtin_fmaf(nzv[e], ngg, bsg));
+                        z = __builtin_fmaxf(z, z * g.slope);
+                        v[e] = __builtin_amdgcn_fmed3f(z, -g.hi, g.hi);
+                    }
+                    const uint4 out = make_uint4(Pair<T>::pack(v[0], v[1]), Pair<T>::pack(v[2], v[3]),
+                                                 Pair<T>::pack(v[4], v[5]), Pair<T>::pack(v[6], v[7]));
+                    // results leave through this wave's own LDS tile: [row o][channel][32 pixels]
+                    *reinterpret_cast<uint4*>(s_out + (o * 32 + lc) * kOutRow + 32 * hh + 16 * gq) = out;
+                }
+            // a lane now moves 8 consecutive pixels, four lanes one run of 32 pixels of a (row, channel): 64 contiguous
+            // bytes per run instead of 64 scattered 16-byte pieces per store instruction
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int run = 16 * k + (lane >> 2), piece = lane & 3, o = k >> 1, ch = run & 31;
+                const uint4 out = *reinterpret_cast<const uint4*>(s_out + run * kOutRow + 16 * piece);
+                const int row = y0 + 2 * rg + o, col = t * TWX - 8 + 32 * sx + 8 * piece;
+                const bool ok = row < g.h && col >= 0 && col < g.wid;
+#ifdef BAND_ABL_NOSTORE
+                asm volatile("" :: "v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
+#else
+                store16(yr, ok ? ((unsigned)(cog * 32 + ch) * uplane + (unsigned)(row * g.wid + col)) * 2u : kOutside, out);
+#endif
+            }
+        };
+
+        // ---- the walk ------------------------------------------------------------------------------------------------
+        Staged<MASK> s0, s1;
+        s0.pn = s1.pn = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();          // the previous item's last reads are done; the zeroed columns are in place
+        issue(0, s0);
+        if constexpr (DEPTH == 2) issue(1, s1);
+        commit(0, s0);
+        __syncthreads();
+
+        // step q: `mine` held image q (committed, free again), `other` holds image q + 1 when loads run two steps ahead
+        auto step = [&](int q, Staged<MASK>& mine, Staged<MASK>& other) {
+            STAMP(q, 0);
+            if (q + DEPTH < Q) issue(q + DEPTH, mine);
+            STAMP(q, 1);
+            if (late && q > 0 && active(q - 1)) epilogue(q - 1);
+            STAMP(q, 2);
+            if (active(q)) {
+                load_rx(q);
+                multiply(q);
+                STAMP(q, 3);
+                if (!late) epilogue(q);
+            }
+            STAMP(q, 4);
+            if (q + 1 < Q) commit(q + 1, DEPTH == 2 ? other : mine);
+            STAMP(q, 5);
             __syncthreads();
+            STAMP(q, 6);
+        };
+        for (int q = 0; q < Q; q += 2) {
+            step(q, s0, s1);
+            if (q + 1 < Q) step(q + 1, s1, s0);
         }
+        if (late && active(Q - 1)) epilogue(Q - 1);
 
         if constexpr (REDUCE) {   // lanes l and l + 32 hold the same channel; then the 8 waves through LDS; one row per band
             red += __shfl_xor(red, 32, 64);
@@ -404,23 +427,22 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
     }
 }
 
-template <class T, int KC, bool MASK, bool REDUCE>
+template <class T, bool MASK, bool REDUCE>
 int launch_band(const BandArgs& g, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(KC + 1) * (band_rows(MASK || REDUCE) + 2) * IW * kPix + 2 * kNoise + 8 * 32 * sizeof(float);
-    static_assert(lds <= 160 * 1024, "band images do not fit the LDS of a CU");
-    auto kernel = band3x3_kernel<T, KC, MASK, REDUCE>;
+    static_assert(kLds <= 160 * 1024, "band images do not fit the LDS of a CU");
+    auto kernel = band3x3_kernel<T, MASK, REDUCE>;
     hipError_t e = allow_large_lds((const void*)kernel);
-    if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", kLds, hipGetErrorString(e));
     const int64_t grid = std::max<int64_t>(8, std::min<int64_t>(((int64_t)g.items + 7) / 8 * 8, compute_units()) / 8 * 8);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kThreads), lds, stream, g);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kThreads), kLds, stream, g);
     return check_launch("sg_conv2d");
 }
 
 template <class T>
 int launch_band_for(const BandArgs& g, hipStream_t stream) {
     const bool red = g.reduce_out != nullptr;
-    if (g.mask_y) return red ? launch_band<T, 1, true, true>(g, stream) : launch_band<T, 1, true, false>(g, stream);
-    return red ? launch_band<T, 1, false, true>(g, stream) : launch_band<T, 1, false, false>(g, stream);
+    if (g.mask_y) return red ? launch_band<T, true, true>(g, stream) : launch_band<T, true, false>(g, stream);
+    return red ? launch_band<T, false, true>(g, stream) : launch_band<T, false, false>(g, stream);
 }
 
 }  // namespace
@@ -431,19 +453,19 @@ bool band3x3_eligible(const sg_conv2d_params& p) {
     const sg_conv2d_phase& ph = p.phase[0];
     if (ph.nky != 3 || ph.nkx != 3 || ph.oy0 != 0 || ph.ox0 != 0 || ph.w_offset != 0 || ph.dy0 != -1 || ph.dx0 != -1) return false;
     if (p.oh != p.h || p.ow != p.w_in) return false;
-    if (p.ci != 32 || (p.co != 32 && p.co != 64)) return false;   // the weights of 32 x 32 channels fill 72 registers
+    if (p.ci != 32 || (p.co != 32 && p.co != 64)) return false;
+    if (!(p.gain > 0.f) || (p.act == 3 && !(p.alpha >= 0.f && p.alpha <= 1.f))) return false;   // the epilogue folds the gain in and takes lrelu as a max   // the weights of 32 x 32 channels fill 72 registers
     if (p.w_in % 8 != 0 || p.w_in < 64 || p.h < 8) return false;
     if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.y) || (p.mask_y && !aligned16(p.mask_y))) return false;
     if (p.reduce_out && !aligned16(p.reduce_x)) return false;
     if (p.in_scale && !aligned16(p.in_scale)) return false;
     if (p.noise && (!aligned16(p.noise) || p.noise_stride_n % 4 != 0)) return false;
     if ((int64_t)std::max(p.ci, p.co) * p.h * p.w_in * 2 >= (int64_t)kOutside) return false;   // byte offsets inside a sample below 2^31
-    const int R = band_rows(p.mask_y != nullptr || p.reduce_out != nullptr);
     const int64_t items = (int64_t)p.n * ((p.h + R - 1) / R) * (p.co / 32);
     return items <= INT32_MAX / 2;
 }
 
-int band3x3_reduce_rows(const sg_conv2d_params& p) { const int R = band_rows(true); return (p.h + R - 1) / R; }   // one row per band of a reducing launch
+int band3x3_reduce_rows(const sg_conv2d_params& p) { return (p.h + R - 1) / R; }   // one row per band
 
 int band3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     BandArgs g;
@@ -451,7 +473,6 @@ int band3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     g.in_scale = p.in_scale; g.out_scale = p.out_scale; g.bias = p.bias;
     g.noise = p.noise; g.noise_gain = p.noise_gain; g.reduce_x = p.reduce_out ? p.reduce_x : nullptr; g.reduce_out = p.reduce_out;
     g.n = p.n; g.ci = p.ci; g.co = p.co; g.h = p.h; g.wid = p.w_in;
-    const int R = band_rows(p.mask_y != nullptr || p.reduce_out != nullptr);
     g.bands = (p.h + R - 1) / R;
     g.cogs = p.co / 32;
     g.items = p.n * g.bands * g.cogs;
@@ -466,3 +487,9 @@ int band3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
 }
 
 }  // namespace sg
+
+#ifdef BAND_ABL_STAMPS
+extern "C" int sg_debug_band_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sg::band_stamps), sizeof(unsigned long long) * 512);
+}
+#endif
