@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('SG_OPS_LIBRARY') or os.path.join(_HERE, 'libsgops.so'
 SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
            'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad', 'sg_upfirdn2d_epilogue',
            'sg_epilogue_backward', 'sg_conv2d_reduce_rows', 'sg_conv2d_kernel', 'sg_conv2d_wgrad_kernel',
-           'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask')
+           'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -68,13 +68,14 @@ def lib():
             fn.restype = ctypes.c_int
         handle.sg_upfirdn2d_epilogue.argtypes = [ctypes.POINTER(Upfirdn2dParams), vp, vp]
         handle.sg_upfirdn2d_epilogue.restype = ctypes.c_int
-        for name in ('sg_conv2d', 'sg_conv2d_wgrad', 'sg_epilogue_backward', 'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask'):     # structs declared in the plugin modules
+        for name in ('sg_conv2d', 'sg_conv2d_wgrad', 'sg_epilogue_backward', 'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask'):     # structs declared in the plugin modules
             getattr(handle, name).argtypes = [vp, vp]
             getattr(handle, name).restype = ctypes.c_int
         handle.sg_conv2d_reduced.argtypes = [vp, vp, vp]
         handle.sg_conv2d_reduced.restype = ctypes.c_int
-        handle.sg_conv2d_supports_mask.argtypes = [vp]
-        handle.sg_conv2d_supports_mask.restype = ctypes.c_int
+        for name in ('sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask'):
+            getattr(handle, name).argtypes = [vp]
+            getattr(handle, name).restype = ctypes.c_int
         handle.sg_conv2d_reduce_rows.argtypes = [vp]
         handle.sg_conv2d_reduce_rows.restype = ctypes.c_int
         handle.sg_conv2d_kernel.argtypes = [vp]

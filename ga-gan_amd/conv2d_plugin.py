@@ -229,12 +229,32 @@ class Conv2dWgradParams(ctypes.Structure):
                 ('n', ctypes.c_int32), ('cx', ctypes.c_int32), ('h', ctypes.c_int32), ('w_in', ctypes.c_int32),
                 ('cg', ctypes.c_int32), ('gh', ctypes.c_int32), ('gw', ctypes.c_int32),
                 ('step', ctypes.c_int32), ('dy0', ctypes.c_int32), ('dx0', ctypes.c_int32),
-                ('nky', ctypes.c_int32), ('nkx', ctypes.c_int32)]
+                ('nky', ctypes.c_int32), ('nkx', ctypes.c_int32),
+                ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float)]
 
 
-def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None):
+def _wgrad_params(x, g, kh, kw, stride, padding, x_scale=None, g_scale=None, dw=None, mask_y=None, mask_alpha=1.0, mask_clamp=-1.0):
+    n, cx, h, w = x.shape
+    _, cg, gh, gw = g.shape
+    return Conv2dWgradParams(x=_lib.ptr(x), g=_lib.ptr(g), dw=_lib.ptr(dw), x_scale=_lib.ptr(x_scale), g_scale=_lib.ptr(g_scale),
+                             dtype=_lib.dtype_code(x), n=n, cx=cx, h=h, w_in=w, cg=cg, gh=gh, gw=gw, step=stride, dy0=-padding,
+                             dx0=-padding, nky=kh, nkx=kw, mask_y=_lib.ptr(mask_y), mask_alpha=mask_alpha, mask_clamp=mask_clamp)
+
+
+def wgrad_supports_mask(x, g, kh, kw, stride=1, padding=0):
+    """True when `conv2d_wgrad(..., mask_y=...)` has a kernel for this geometry."""
+    if not (x.is_cuda and g.is_cuda) or x.dim() != 4 or g.dim() != 4 or x.dtype != g.dtype or x.dtype not in _DTYPE_NAME:
+        return False
+    if not x.is_contiguous() or not g.is_contiguous():
+        return False
+    p = _wgrad_params(x, g, kh, kw, stride, padding, mask_y=g)
+    return bool(_lib.lib().sg_conv2d_wgrad_supports_mask(ctypes.byref(p)))
+
+
+def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None, mask_y=None, mask_alpha=1.0, mask_clamp=-1.0):
     """dw[cg, cx, kh, kw] (float32) = sum_{n,a,b} g[n,cg,a,b] * x[n,cx,a*stride+ky-padding,b*stride+kx-padding],
-    with optional per-sample channel scales on both operands.  For y = conv2d(x, w, stride, padding) pass
+    with optional per-sample channel scales on both operands and an optional activation mask on g (`mask_y`: as in
+    `conv2d`; ask `wgrad_supports_mask` first).  For y = conv2d(x, w, stride, padding) pass
     g = dy; for y = conv_transpose2d(x, w[ci, co]) pass (x=dy, g=x), which yields dw in w's [ci, co] layout."""
     if not (x.is_cuda and g.is_cuda):
         raise RuntimeError('x and g must reside on CUDA device')
@@ -249,13 +269,13 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None):
             raise RuntimeError(f'{name} must be a dense float32 tensor of shape {shape}')
     dw = torch.zeros([kh, kw, cg, cx], dtype=torch.float32, device=x.device)
     if n > 0:
-        p = Conv2dWgradParams(x=_lib.ptr(x), g=_lib.ptr(g), dw=_lib.ptr(dw), x_scale=_lib.ptr(x_scale),
-                              g_scale=_lib.ptr(g_scale), dtype=_lib.dtype_code(x), n=n, cx=cx, h=h, w_in=w, cg=cg,
-                              gh=gh, gw=gw, step=stride, dy0=-padding, dx0=-padding, nky=kh, nkx=kw)
+        if mask_y is not None and (mask_y.shape != g.shape or mask_y.dtype != g.dtype or not mask_y.is_contiguous()):
+            raise RuntimeError('mask_y must be dense and match g')
+        p = _wgrad_params(x, g, kh, kw, stride, padding, x_scale, g_scale, dw, mask_y, mask_alpha, mask_clamp)
         label = ''
         if _lib.profiling():
             name = _lib.lib().sg_conv2d_wgrad_kernel(ctypes.byref(p)).decode()
-            taps = '' if name in ('wgrad3x3_kernel', 'wgrad_f32_kernel') else f',{1 if kh * kw <= 1 else 4 if kh * kw <= 4 else 9}'
+            taps = '' if name in ('wgrad3x3_kernel', 'wgrad_f32_kernel', 'wgrad1x1_few_kernel') else f',{1 if kh * kw <= 1 else 4 if kh * kw <= 4 else 9}'
             label = f'{name}<{_DTYPE_NAME[x.dtype]}{taps}>' if name != 'wgrad_f32_kernel' else name
         if _DETAIL and label:
             label += f' k{kh} {cx}->{cg} g{gh}x{gw} step{stride} n{n}'

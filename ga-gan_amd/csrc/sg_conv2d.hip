@@ -1076,6 +1076,7 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
                SG_ERR_INVALID_ARGUMENT, "conv2d: tensor is too large");
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->w && p->y, SG_ERR_NULL_POINTER, "conv2d: x, w and y must not be NULL");
+    if (conv1x1_few_eligible(*p)) return conv1x1_few_launch(*p, (hipStream_t)stream);
     if (band3x3_eligible(*p)) return band3x3_launch(*p, (hipStream_t)stream);
     SG_REQUIRE(p->mask_y == nullptr, SG_ERR_UNSUPPORTED, "conv2d: no kernel applies an input mask for this geometry");
     if (conv3x3_eligible(*p)) return conv3x3_launch(*p, (hipStream_t)stream);
@@ -1100,6 +1101,8 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
                SG_ERR_INVALID_ARGUMENT, "conv2d_wgrad: tensor is too large");
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->g && p->dw, SG_ERR_NULL_POINTER, "conv2d_wgrad: x, g and dw must not be NULL");
+    if (wgrad1x1_few_eligible(*p)) return wgrad1x1_few_launch(*p, (hipStream_t)stream);
+    SG_REQUIRE(p->mask_y == nullptr, SG_ERR_UNSUPPORTED, "conv2d_wgrad: no kernel applies a gradient mask for this geometry");
     if (wgrad3x3_eligible(*p)) return wgrad3x3_launch(*p, (hipStream_t)stream);
     if (wgrad_f32_eligible(*p)) return wgrad_f32_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
@@ -1112,6 +1115,7 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
 
 extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
     if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return -1;
+    if (sg::conv1x1_few_eligible(*p)) return sg::conv1x1_few_reduce_rows(*p);
     if (sg::band3x3_eligible(*p)) return sg::band3x3_reduce_rows(*p);
     if (sg::conv3x3_eligible(*p)) return sg::conv3x3_reduce_rows(*p);
     int taps = 0;
@@ -1123,11 +1127,19 @@ extern "C" int sg_conv2d_supports_mask(const sg_conv2d_params* p) {
     if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return 0;
     sg_conv2d_params q = *p;
     if (q.mask_y == nullptr) q.mask_y = q.x;
-    return sg::band3x3_eligible(q) ? 1 : 0;
+    return (sg::conv1x1_few_eligible(q) || sg::band3x3_eligible(q)) ? 1 : 0;
+}
+
+extern "C" int sg_conv2d_wgrad_supports_mask(const sg_conv2d_wgrad_params* p) {
+    if (p == nullptr) return 0;
+    sg_conv2d_wgrad_params q = *p;
+    if (q.mask_y == nullptr) q.mask_y = q.g;
+    return sg::wgrad1x1_few_eligible(q) ? 1 : 0;
 }
 
 extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
     if (p == nullptr) return "";
+    if (sg::conv1x1_few_eligible(*p)) return "conv1x1_few_kernel";
     if (sg::band3x3_eligible(*p)) return "band3x3_kernel";
     if (sg::conv_up2_eligible(*p)) return "conv_up2_kernel";
     if (!sg::conv3x3_eligible(*p)) return "conv2d_mfma_kernel";
@@ -1136,6 +1148,7 @@ extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
 
 extern "C" const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p) {
     if (p == nullptr) return "";
+    if (sg::wgrad1x1_few_eligible(*p)) return "wgrad1x1_few_kernel";
     if (sg::wgrad3x3_eligible(*p)) return "wgrad3x3_kernel";
     return sg::wgrad_f32_eligible(*p) ? "wgrad_f32_kernel" : "conv2d_wgrad_kernel";
 }

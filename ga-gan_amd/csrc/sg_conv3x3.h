@@ -33,6 +33,13 @@ bool band3x3_eligible(const sg_conv2d_params& p);
 int band3x3_launch(const sg_conv2d_params& p, hipStream_t stream);
 int band3x3_reduce_rows(const sg_conv2d_params& p);
 
+// 1x1 convolutions with at most 4 channels on one side as streaming kernels, and their weight gradient (sg_conv1x1_few.hip).
+bool conv1x1_few_eligible(const sg_conv2d_params& p);
+int conv1x1_few_launch(const sg_conv2d_params& p, hipStream_t stream);
+int conv1x1_few_reduce_rows(const sg_conv2d_params& p);
+bool wgrad1x1_few_eligible(const sg_conv2d_wgrad_params& p);
+int wgrad1x1_few_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
+
 // Transposed 3x3 stride-2 convolution as one unit-stride contraction over the 2 x 2 input window (sg_convup.hip).
 bool conv_up2_eligible(const sg_conv2d_params& p);
 int conv_up2_launch(const sg_conv2d_params& p, hipStream_t stream);

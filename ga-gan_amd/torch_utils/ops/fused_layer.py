@@ -133,21 +133,27 @@ class _FusedConv(torch.autograd.Function):
         want_ds = need[2] and styles is not None
         want_dx = need[0] or want_ds
         dy = dy.contiguous()
-        # Data gradient with the activation mask applied to dy while the kernel stages it: no dz tensor.  Taken when
-        # nothing else needs dz (the weight gradient does) and a kernel exists for the geometry.
-        if mode == 'same' and want_dx and not need[1] and y is not None:
+        # The activation mask applied to dy while the kernels stage it: no dz tensor.  Taken when a masking kernel
+        # exists for every gradient that is wanted (data gradient, weight gradient) at this geometry.
+        if mode == 'same' and y is not None and (want_dx or need[1]):
             plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
-            if tuple(x.shape[2:]) == plan.out_size(*dy.shape[2:]) and _conv.supports_mask(dy, plan, ci, reduce=want_ds):
+            ok = not want_dx or (tuple(x.shape[2:]) == plan.out_size(*dy.shape[2:]) and _conv.supports_mask(dy, plan, ci, reduce=want_ds))
+            ok = ok and (not need[1] or _conv.wgrad_supports_mask(x, dy, k, k, stride=stride, padding=padding))
+            if ok:
+                mask = dict(mask_y=y, mask_alpha=alpha if act == 'lrelu' else 1.0, mask_clamp=clamp)
                 ddcoefs = dng = dbias = None
                 if any(want.values()):
                     _, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y, want_dz=False, **want, **ep)
-                dx = _conv.conv2d(dy, plan.pack(w, transposed_layout=True), plan, ci, in_scale=dcoefs, out_scale=styles, gain=gain,
-                                  reduce_x=x if want_ds else None, mask_y=y, mask_alpha=alpha if act == 'lrelu' else 1.0,
-                                  mask_clamp=clamp)
-                if want_ds:
-                    dx, dstyles = dx
-                    dstyles = dstyles * gain      # the reduction is taken before the output scale and gain
-                return (dx if need[0] else None, None, dstyles, ddcoefs, None,
+                if want_dx:
+                    dx = _conv.conv2d(dy, plan.pack(w, transposed_layout=True), plan, ci, in_scale=dcoefs, out_scale=styles, gain=gain,
+                                      reduce_x=x if want_ds else None, **mask)
+                    if want_ds:
+                        dx, dstyles = dx
+                        dstyles = dstyles * gain      # the reduction is taken before the output scale and gain
+                if need[1]:
+                    dw = (_conv.conv2d_wgrad(x, dy, k, k, stride=stride, padding=padding, x_scale=styles, g_scale=dcoefs, **mask)
+                          * gain).to(w.dtype)
+                return (dx if need[0] else None, dw, dstyles, ddcoefs, None,
                         dng.reshape(noise_strength.shape) if dng is not None else None,
                         dbias.to(bias.dtype) if dbias is not None else None, None, None)
         dz, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y if y is not None else dy, **want, **ep)

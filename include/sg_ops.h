@@ -256,8 +256,10 @@ int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t 
 /* Name of the device kernel sg_conv2d runs for this geometry (the symbol a profiler reports, without template
  * arguments).  For 16-bit tensors whose rows are whole aligned packets: "conv3x3_kernel" (3x3, output step 1,
  * input step 1 or 2), "conv3x3_resident_kernel" (the same with at most 64 channels on both sides: the weights
- * stay in LDS), "conv_up2_kernel" (3x3 transposed, stride 2, no epilogue), "band3x3_kernel" (3x3 same-size, 32 or 64
- * channels on both sides: persistent row bands with the weights in registers); "conv2d_mfma_kernel" otherwise.
+ * stay in LDS), "conv_up2_kernel" (3x3 transposed, stride 2, no epilogue), "band3x3_kernel" (3x3 same-size, 32 input
+ * and 32 or 64 output channels: persistent row bands with the weights in registers), "conv1x1_few_kernel" (1x1 with at
+ * most 4 channels on one side, planes of at least 4096 pixels: streaming kernels on the vector units);
+ * "conv2d_mfma_kernel" otherwise.
  * Static storage. */
 const char* sg_conv2d_kernel(const sg_conv2d_params* p);
 
@@ -283,11 +285,20 @@ typedef struct sg_conv2d_wgrad_params {
     int32_t dtype;
     int32_t n, cx, h, w_in, cg, gh, gw;
     int32_t step, dy0, dx0, nky, nkx;
+    /* optional mask on the gradient operand g, as sg_conv2d_params.mask_y: g is the gradient that arrived at the output
+     * of a layer with a fused epilogue, mask_y that output as saved by the forward pass (g's shape and dtype); the
+     * kernel contracts g * m.  NULL = none.  Ask sg_conv2d_wgrad_supports_mask() first. */
+    const void* mask_y;
+    float mask_alpha, mask_clamp;
 } sg_conv2d_wgrad_params;
 
 int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stream);
 
-/* Name of the device kernel sg_conv2d_wgrad runs for this geometry: "wgrad3x3_kernel" (16-bit, 3x3, step 1 or 2,
+/* 1 when sg_conv2d_wgrad honours p->mask_y for this geometry (decided as if mask_y were set), else 0. */
+int sg_conv2d_wgrad_supports_mask(const sg_conv2d_wgrad_params* p);
+
+/* Name of the device kernel sg_conv2d_wgrad runs for this geometry: "wgrad1x1_few_kernel" (16-bit, 1x1, at most 4
+ * channels on one side and at least 8 on the other, planes of at least 4096 pixels), "wgrad3x3_kernel" (16-bit, 3x3, step 1 or 2,
  * at least 32 channels on both sides, rows of whole packets, gradient planes 32 pixels wide or more),
  * "wgrad_f32_kernel" (float32, 1x1 or 3x3, at least 32 channels on both sides) or "conv2d_wgrad_kernel".  Static storage. */
 const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p);
