@@ -10,11 +10,19 @@ batch is per-GPU batch x N).  Default workload: FFHQ-256 Affine+ at batch 32 per
 with the four highest resolutions in bfloat16.  Inputs are resident in HBM before
 the timed region starts.  Rank 0 prints ONE JSON line.
 
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL).
+The same line carries the 1024^2 half of the metric under "workloads" (FFHQ-1024 AffineLight+, batch 16 per GPU,
+timed the same way after the headline workload).
+
+For N > 1 either launch with torch.distributed.run (one rank per GPU, RCCL), or run `python bench.py --gpus N`
+as is: without WORLD_SIZE in the environment the process starts the N ranks itself, as the reference's entry
+point spawns one process per GPU (train.py:691-696), and exits with the first non-zero status among them.
 """
 import argparse
 import json
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,6 +51,9 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=16)
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--also', default='c3', help='second workload timed after the headline one and reported under '
+                    '"workloads" (the 1024^2 half of the metric); "none" to skip')
+    ap.add_argument('--also-steps', type=int, default=0, help='timed steps of the second workload (default: --steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--ada', action='store_true',
@@ -54,9 +65,9 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_trainer(args, rank, world):
+def make_trainer(args, rank, world, config=None):
     from ga_gan_amd.training import training_loop
-    desc, cfg, res, batch_gpu, par = CONFIGS[args.config]
+    desc, cfg, res, batch_gpu, par = CONFIGS[config or args.config]
     opts = training_loop.setup_training_options(cfg=cfg, resolution=res, batch_size=batch_gpu * world, num_gpus=world,
                                                 batch_gpu=batch_gpu, glrate=0.02 if par != 'FULL' else None,
                                                 **getattr(training_loop, par))
@@ -68,12 +79,19 @@ def make_trainer(args, rank, world):
             desc + (' + ADA (bgc)' if extra else ''), res, batch_gpu)
 
 
+def traffic_file():
+    """The newest committed counter summary (profiles/rN_traffic.json), or None."""
+    names = sorted(n for n in os.listdir(os.path.join(ROOT, 'profiles')) if n.endswith('_traffic.json')) \
+        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+    return os.path.join(ROOT, 'profiles', names[-1]) if names else None
+
+
 def measured_traffic(label):
     """HBM-side bytes per launch of the kernel `label` (symbol<dtype>) from the committed counter runs of this same
     command (profiles/r1_traffic.json, written by tools/summarize_traffic.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
     passes); None when the file has no entry.  All template instances of the symbol and dtype are pooled."""
-    path = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
-    if not os.path.isfile(path):
+    path = traffic_file()
+    if path is None:
         return None
     symbol, _, dtype = label.partition('<')
     dtype = dtype.rstrip('>').split(',')[0]
@@ -83,6 +101,14 @@ def measured_traffic(label):
             total += v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch'])
             launches += v['launches']
     return int(total / launches) if launches else None
+
+
+def traffic_source(label):
+    """Where `roofline.traffic` comes from: it is not measured in this run (counters need rocprofv3 passes of their own)."""
+    path = traffic_file()
+    if path is None or measured_traffic(label) is None:
+        return None
+    return 'profiles/%s: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, per launch' % os.path.basename(path)
 
 
 def kernel_roofline(trainer, real, real_c, steps):
@@ -113,13 +139,13 @@ def kernel_roofline(trainer, real, real_c, steps):
         peak = MFMA_PEAK_TFLOPS['float' if '<float' in name else 'bf16']
         achieved = (k['flops'] / k['launches']) / (avg_ms * 1e-3) / 1e12
         roofline = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 4), traffic=measured_traffic(name), launches=k['launches'],
+                        frac=round(achieved / peak, 4), traffic=measured_traffic(name), traffic_source=traffic_source(name), launches=k['launches'],
                         avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_flops_per_launch=int(k['flops'] / k['launches']),
                         algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
     else:
         achieved = (k['bytes'] / k['launches']) / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(name), launches=k['launches'],
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(name), traffic_source=traffic_source(name), launches=k['launches'],
                         avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
     summary = {n: dict(launches_per_step=v['launches'] // steps, ms_per_step=round(v['ms'] / steps, 3),
                        gbps=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1),
@@ -128,10 +154,21 @@ def kernel_roofline(trainer, real, real_c, steps):
     return roofline, summary
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or 'unknown'
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the reference's fallback path) on this host's cores: FFHQ-256 Affine+,
-    batch 4, float32.  Bounded sample: one Gmain warm-up, then one timed pass of each phase; an average
-    iteration costs Gmain + Dmain + Greg/4 + Dreg/16."""
+    batch 4, float32 (BASELINE config 1).  Bounded sample: 3 warm-up passes, then 3 timed passes of each of the
+    four phases on all cores (an average iteration costs Gmain + Dmain + Greg/4 + Dreg/16), and one Gmain pass on
+    a single thread, from which the single-thread rate is scaled."""
     from ga_gan_amd.training import networks, training_loop
     from oracle import objectives
     from oracle import stylegan2 as sg
@@ -154,9 +191,8 @@ def cpu_baseline():
     z = torch.randn(4, 512, generator=torch.Generator().manual_seed(0))
     c = torch.zeros(4, 0)
     real = torch.randint(0, 256, [4, 3, 256, 256], generator=torch.Generator().manual_seed(1)).float() / 127.5 - 1
-    times = {}
-    for phase, gain in (('warm', 1), ('Gmain', 1), ('Dmain', 1), ('Greg', 4), ('Dreg', 16)):
-        name = 'Gmain' if phase == 'warm' else phase
+
+    def one_pass(name, gain):
         params, names = (gp, g_names) if name[0] == 'G' else (dp, d_names)
         for t in list(gp.values()) + list(dp.values()):
             t.requires_grad_(False)
@@ -165,30 +201,54 @@ def cpu_baseline():
             params[n].requires_grad_(True)
         t0 = time.perf_counter()
         obj.accumulate_gradients(name, real, c, z, c, gain)
-        times[phase] = time.perf_counter() - t0
+        return time.perf_counter() - t0
+
+    gains = dict(Gmain=1, Dmain=1, Greg=4, Dreg=16)
+    for name in ('Gmain', 'Dmain', 'Gmain'):
+        one_pass(name, gains[name])
+    timed = 3
+    times = {name: sum(one_pass(name, gain) for _ in range(timed)) / timed for name, gain in gains.items()}
     per_iter = times['Gmain'] + times['Dmain'] + times['Greg'] / 4 + times['Dreg'] / 16
+    torch.set_num_threads(1)
+    gmain_1t = one_pass('Gmain', 1)
+    torch.set_num_threads(cores)
     return dict(value=round(4 / per_iter, 4), unit='img/s', cores=cores, kind='port',
-                sample='FFHQ-256 Affine+ batch 4 fp32 on CPU: 1 warm-up + one pass of each phase '
-                       '(Gmain %.2fs, Dmain %.2fs, Greg %.2fs, Dreg %.2fs); iteration = Gmain+Dmain+Greg/4+Dreg/16'
-                       % (times['Gmain'], times['Dmain'], times['Greg'], times['Dreg']))
+                value_1_thread=round(4 / (per_iter * gmain_1t / times['Gmain']), 4), cpu=cpu_model(), torch=torch.__version__,
+                sample='FFHQ-256 Affine+ batch 4 fp32 on CPU: 3 warm-up passes + %d timed passes of each phase on %d threads '
+                       '(Gmain %.2fs, Dmain %.2fs, Greg %.2fs, Dreg %.2fs); iteration = Gmain+Dmain+Greg/4+Dreg/16; '
+                       '1 thread: one Gmain pass (%.2fs), iteration scaled by the same ratio'
+                       % (timed, cores, times['Gmain'], times['Dmain'], times['Greg'], times['Dreg'], gmain_1t))
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: no GPU is visible')
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run'
-    torch.backends.cudnn.benchmark = os.environ.get('SG_MIOPEN_FIND', '0') == '1'
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start one rank per GPU from this process, which has not touched the GPU
+    (counting devices does not initialise it), wait for all of them, exit with the first failure."""
+    import torch.cuda
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} needs {args.gpus} GPUs: {have} visible')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', str(port)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    status = 0
+    for proc in procs:
+        rc = proc.wait()
+        if rc != 0 and status == 0:
+            status = rc
+            for other in procs:          # a rank that died leaves the others waiting in a collective
+                if other.poll() is None:
+                    other.terminate()
+    return status
 
-    from ga_gan_amd.torch_utils import training_stats
-    trainer, desc, res, batch_gpu = make_trainer(args, rank, world)
+
+def run_workload(args, config, steps, warmup, rank, world, local_rank, note, with_roofline):
+    """Warm up, time `steps` iterations between barriers, MAX over ranks.  -> dict for the JSON line."""
+    trainer, desc, res, batch_gpu = make_trainer(args, rank, world, config)
     gen = torch.Generator(device=trainer.device).manual_seed(1 + rank)
     real, real_c = trainer.synthetic_batch(gen)          # resident in HBM before timing
 
@@ -198,20 +258,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def note(msg):   # progress on stderr (the JSON line is the only thing on stdout)
-        if rank == 0:
-            print(f'[bench +{time.perf_counter() - t_start:7.1f}s] {msg}', file=sys.stderr, flush=True)
-
-    t_start = time.perf_counter()
-    note(f'{desc}; world {world}; warm-up {args.warmup} steps')
-    for i in range(args.warmup):
+    note(f'{desc}; world {world}; warm-up {warmup} steps')
+    for i in range(warmup):
         trainer.step(real, real_c)
         torch.cuda.synchronize()
         note(f'warm-up step {i} done')
     barrier()
-    note(f'timing {args.steps} steps')
+    note(f'timing {steps} steps')
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         trainer.step(real, real_c)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -219,12 +274,60 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=trainer.device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-
     note(f'timed region: {elapsed:.3f}s')
     roofline, kernels = (None, {})
-    if not args.no_roofline:
-        roofline, kernels = kernel_roofline(trainer, real, real_c, min(args.steps, 4))
+    if with_roofline:
+        roofline, kernels = kernel_roofline(trainer, real, real_c, min(steps, 4))
         barrier()
+    global_batch = batch_gpu * world
+    out = dict(value=round(steps * global_batch / elapsed, 3), unit='img/s', steps=steps, warmup=warmup,
+               ms_per_step=round(elapsed / steps * 1e3, 3),
+               config=dict(workload=desc, resolution=res, global_batch=global_batch, per_gpu_batch=batch_gpu,
+                           parallelism=f'dp{world}', hip_graphs=bool(trainer.use_graphs),
+                           iteration='Gmain+Dmain every step, Greg every 4th, Dreg every 16th',
+                           activations='bf16 in the four highest resolutions (images within 3e-2 relative L2 of the float32 '
+                                       'reference path; float32 runs within 1e-3)',
+                           kernels='conv2d / conv3x3 / band3x3 / wgrad (MFMA), 1x1 to-RGB / from-RGB streaming kernels, upfirdn2d, '
+                                   'layer epilogues, bias_act, minibatch-std: hand-written HIP; small GEMMs: torch'),
+               roofline=roofline, kernels=kernels,
+               grad_exchange_bytes_per_step=int(trainer.exchanged_bytes / max(trainer.batch_idx, 1)))
+    del trainer, real, real_c
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE is {world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no GPU is visible')
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f'bench.py --gpus {args.gpus} needs {args.gpus} GPUs: {torch.cuda.device_count()} visible')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.backends.cudnn.benchmark = os.environ.get('SG_MIOPEN_FIND', '0') == '1'
+
+    from ga_gan_amd.torch_utils import training_stats
+    t_start = time.perf_counter()
+
+    def note(msg):   # progress on stderr (the JSON line is the only thing on stdout)
+        if rank == 0:
+            print(f'[bench +{time.perf_counter() - t_start:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+    main_wl = run_workload(args, args.config, args.steps, args.warmup, rank, world, local_rank, note, not args.no_roofline)
+    workloads = {}
+    if args.also != 'none' and args.also != args.config:
+        also_steps = args.also_steps or args.steps
+        wl = run_workload(args, args.also, also_steps, min(args.warmup, 3), rank, world, local_rank, note, not args.no_roofline)
+        workloads[args.also] = wl
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         training_stats.enable(False)
@@ -233,15 +336,11 @@ def main():
         note('CPU baseline done')
 
     if rank == 0:
-        global_batch = batch_gpu * world
-        out = dict(metric='training images/sec', value=round(args.steps * global_batch / elapsed, 3), unit='img/s',
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload=desc, resolution=res, global_batch=global_batch, per_gpu_batch=batch_gpu,
-                               parallelism=f'dp{world}', hip_graphs=bool(trainer.use_graphs), iteration='Gmain+Dmain every step, Greg every 4th, Dreg every 16th',
-                               kernels='conv2d / conv3x3 / wgrad (MFMA), upfirdn2d, layer epilogues, bias_act, minibatch-std: hand-written HIP; small GEMMs: torch'),
-                   roofline=roofline, cpu_baseline=baseline, kernels=kernels,
-                   grad_exchange_bytes_per_step=int(trainer.exchanged_bytes / max(trainer.batch_idx, 1)))
+        out = dict(metric='training images/sec', value=main_wl['value'], unit='img/s', n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=main_wl['ms_per_step'], higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='bf16', data='synthetic', config=main_wl['config'], roofline=main_wl['roofline'], cpu_baseline=baseline,
+                   kernels=main_wl['kernels'], workloads=workloads,
+                   grad_exchange_bytes_per_step=main_wl['grad_exchange_bytes_per_step'])
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

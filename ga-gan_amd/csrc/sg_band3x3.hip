@@ -457,7 +457,7 @@ bool band3x3_eligible(const sg_conv2d_params& p) {
     if (!(p.gain > 0.f) || (p.act == 3 && !(p.alpha >= 0.f && p.alpha <= 1.f))) return false;   // the epilogue folds the gain in and takes lrelu as a max   // the weights of 32 x 32 channels fill 72 registers
     if (p.w_in % 8 != 0 || p.w_in < 64 || p.h < 8) return false;
     if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.y) || (p.mask_y && !aligned16(p.mask_y))) return false;
-    if (p.reduce_out && !aligned16(p.reduce_x)) return false;
+    if (!aligned16(p.reduce_x)) return false;   // (NULL passes)
     if (p.in_scale && !aligned16(p.in_scale)) return false;
     if (p.noise && (!aligned16(p.noise) || p.noise_stride_n % 4 != 0)) return false;
     if ((int64_t)std::max(p.ci, p.co) * p.h * p.w_in * 2 >= (int64_t)kOutside) return false;   // byte offsets inside a sample below 2^31

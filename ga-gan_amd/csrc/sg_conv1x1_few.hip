@@ -317,14 +317,15 @@ bool common_ok(const sg_conv2d_params& p) {
     if (((int64_t)p.h * p.w_in) % 8 != 0 || (int64_t)p.h * p.w_in < 4096) return false;   // small planes: launch-bound either way
     if (p.noise) return false;
     if (!(p.gain > 0.f) || (p.act == 3 && !(p.alpha >= 0.f && p.alpha <= 1.f))) return false;
-    if (!aligned16(p.x) || !aligned16(p.y) || (p.mask_y && !aligned16(p.mask_y)) || (p.reduce_out && !aligned16(p.reduce_x))) return false;
+    if (!aligned16(p.x) || !aligned16(p.y) || (p.mask_y && !aligned16(p.mask_y)) || !aligned16(p.reduce_x)) return false;
     return (int64_t)p.h * p.w_in / 8 <= INT32_MAX;
 }
 
 FewArgs few_args(const sg_conv2d_params& p) {
     FewArgs g;
     g.x = p.x; g.mask_y = p.mask_y; g.w = p.w; g.y = p.y;
-    g.in_scale = p.in_scale; g.out_scale = p.out_scale; g.bias = p.bias; g.reduce_x = p.reduce_x; g.reduce_out = p.reduce_out;
+    g.in_scale = p.in_scale; g.out_scale = p.out_scale; g.bias = p.bias;
+    g.reduce_x = p.reduce_out ? p.reduce_x : nullptr; g.reduce_out = p.reduce_x ? p.reduce_out : nullptr;
     g.n = p.n; g.ci = p.ci; g.co = p.co;
     g.packets = (int)((int64_t)p.h * p.w_in / 8);
     g.slope = (p.act == 3) ? p.alpha : 1.f;
@@ -382,11 +383,12 @@ int launch_few(const sg_conv2d_params& p, hipStream_t stream) {
 bool conv1x1_few_eligible(const sg_conv2d_params& p) {
     if (!common_ok(p)) return false;
     if (p.co <= 4 && p.ci > 4) {                                   // few_out
-        return p.ci <= kFewOutMaxCi && !p.mask_y && !p.reduce_out;
+        return p.ci <= kFewOutMaxCi && !p.mask_y && !p.reduce_x;
     }
     if (p.ci <= 4 && p.co > 4) {                                   // few_in
         if (p.co > 1024) return false;
-        if (p.reduce_out && p.co != 32 && p.co != 64) return false;
+        // (decided by reduce_x, which callers set before they size reduce_out with sg_conv2d_reduce_rows)
+        if (p.reduce_x && p.co != 32 && p.co != 64) return false;
         return true;
     }
     return false;

@@ -518,7 +518,7 @@ bool conv3x3_eligible(const sg_conv2d_params& p) {
     if (p.w_in % 8 != 0 || p.ow % 4 != 0 || p.ci % 8 != 0) return false;
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
     const auto aligned8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
-    if (!aligned8(p.y) || (p.reduce_out && !aligned8(p.reduce_x))) return false;
+    if (!aligned8(p.y) || !aligned8(p.reduce_x)) return false;   // reduce_x, not reduce_out: callers size reduce_out from this answer
     if (p.noise && (!aligned16(p.noise) || p.noise_stride_n % 4 != 0)) return false;
     // Unit stride with one or two chunks goes to the weights-resident kernel when the output is narrow too; a wide
     // output with a narrow input stays on the general kernel.  The strided form wins from 32 channels.
