@@ -91,6 +91,15 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_limit=1e5):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, grad_limit=grad_limit))
 
+    def load_state_dict(self, state_dict):
+        """As torch.optim.Optimizer.load_state_dict; the step counts are brought back to the host afterwards (a
+        snapshot read with map_location=<device> carries them as device tensors, and `step()` reads each count on
+        the host: one blocking device read per parameter and step otherwise)."""
+        super().load_state_dict(state_dict)
+        for state in self.state.values():
+            if isinstance(state.get('step'), torch.Tensor) and state['step'].device.type != 'cpu':
+                state['step'] = state['step'].detach().to('cpu', torch.float32)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

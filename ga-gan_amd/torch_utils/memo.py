@@ -13,7 +13,8 @@ valid while every tensor of `sources` keeps its storage and version counter (in-
 optimizer steps, `load_state_dict`, EMA updates - advance the counter).  Values that need a
 gradient graph (a source requires grad while grad mode is on) are never cached.  Tensors
 handed out by `derived` are constants: `memo(t, key, fn)` attaches further derived values
-(flips, transposes, packings) to them.
+(flips, transposes, packings) to them, except while `t` requires grad in grad mode (then `fn()`
+is evaluated in the open, as part of the caller's graph).
 """
 import torch
 
@@ -45,6 +46,8 @@ def memo(t, key, fn):
     """`fn()` - a pure function of the tensor `t` - computed once if `t` is a constant."""
     cache = getattr(t, '_sg_memo', None)
     if cache is None or (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return fn()
+    if torch.is_grad_enabled() and t.requires_grad:   # the caller wants a graph through fn: a cached value has none
         return fn()
     hit = cache.get(key)
     if hit is None:

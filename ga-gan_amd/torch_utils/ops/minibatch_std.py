@@ -11,6 +11,9 @@ from ... import _lib
 from .. import misc
 
 
+MAX_KERNEL_GROUP = 64   # samples per group the kernels hold (sg_mbstd rejects larger groups)
+
+
 def _composite(x, group_size, num_channels):
     n, c, h, w = x.shape
     g = min(group_size, n) if group_size is not None else n
@@ -32,7 +35,6 @@ def _call(fn_name, x, dy, out, g, f):
 class _MinibatchStd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, f):
-        x = x.contiguous()
         n, c, h, w = x.shape
         y = torch.empty([n, c + f, h, w], dtype=x.dtype, device=x.device)
         _call('sg_mbstd_forward', x, None, y, g, f)
@@ -62,4 +64,8 @@ def minibatch_std(x, group_size, num_channels=1):
     g = min(int(group_size), n) if group_size is not None else n
     if n % g != 0 or c % num_channels != 0:
         raise RuntimeError(f'minibatch_std: batch {n} / channels {c} not divisible by group {g} / sets {num_channels}')
-    return _MinibatchStd.apply(x, g, num_channels)
+    if g > MAX_KERNEL_GROUP:     # (whole-batch groups of a large batch: the tensor ops of the reference)
+        return _composite(x, g, num_channels)
+    # made contiguous here, inside the caller's graph: the copy the function would make itself is a new leaf, and
+    # the second-order term through the statistic would end at it
+    return _MinibatchStd.apply(x.contiguous(), g, num_channels)

@@ -59,6 +59,8 @@ class StyleGAN2Loss(Loss):
             known = type(self.D).__module__.endswith('training.networks') and type(self.D).__name__ == 'Discriminator'
             layers = [m for m in self.D.modules() if type(m).__name__ == 'MinibatchStdLayer']
             self._mbstd_sizes = [m.group_size for m in layers] if known else [None]
+        if self._mbstd_sizes != [None] and (n_gen + n_real) * self.D.largest_activation_elements() > 2 ** 31 - 1:
+            return None              # one pass would make a tensor beyond the kernels' 32-bit indexing: two passes
         group = None
         for size in self._mbstd_sizes:
             if size is None or size > n_gen or n_gen % size != 0 or (group is not None and size != group):

@@ -891,6 +891,17 @@ class Discriminator(torch.nn.Module):
         self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs,
                                         **common_kwargs)
 
+    def largest_activation_elements(self):
+        """Upper bound of the elements per sample of the largest tensor a pass makes (the first block's: its channels
+        at the image resolution plus the blur's margin).  The kernels index a tensor with 32 bits, so callers that
+        choose their own batch (the loss, when it puts both halves of Dmain through one pass) keep batch x this
+        below 2**31."""
+        largest = 0
+        for res in self.block_resolutions:
+            out_channels, tmp_channels = getattr(self, f'b{res}').conv1.weight.shape[:2]
+            largest = max(largest, max(tmp_channels, self.img_channels) * (res + 2) ** 2, out_channels * (res // 2) ** 2)
+        return largest
+
     def forward(self, img, c, **block_kwargs):
         x = None
         for res in self.block_resolutions:

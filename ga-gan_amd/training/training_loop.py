@@ -17,6 +17,7 @@ a few MB instead of the whole network.
 """
 import copy
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -318,7 +319,16 @@ class Trainer:
                 self.ada_stats = training_stats.Collector(regex='Loss/signs/real')
         self.reducer = GradReducer(num_gpus)
         self.reducer.attach(list(self.G.parameters()) + list(self.D.parameters()))
-        self.loss.grad_sync = None if use_graphs else self.reducer   # (a recorded phase exchanges after its replay)
+        # HIP graphs: the forward/backward of a phase is recorded once (after its first eager run) and replayed
+        # afterwards, which removes the launch cost of its few thousand small kernels from the host.  Every phase
+        # runs the augmentation pipe in front of the discriminator, and the pipe draws its per-image parameters and
+        # padding sizes on the host: a recording would freeze them (and the strength p), so with a pipe the phases
+        # are launched from the host as usual.
+        if use_graphs and augment_pipe is not None:
+            warnings.warn('use_graphs is ignored while an augment_pipe is set: the pipe draws its parameters on the host')
+            use_graphs = False
+        self.use_graphs = bool(use_graphs)
+        self.loss.grad_sync = None if self.use_graphs else self.reducer   # (a recorded phase exchanges after its replay)
         self.phases = []
         for name, module, opt_kwargs, reg_interval in (('G', self.G, G_opt_kwargs, G_reg_interval),
                                                        ('D', self.D, D_opt_kwargs, D_reg_interval)):
@@ -336,9 +346,6 @@ class Trainer:
         self.cur_nimg = 0
         self.batch_idx = 0
         self.exchanged_bytes = 0
-        # HIP graphs: the forward/backward of a phase is recorded once (after its first eager run) and replayed
-        # afterwards, which removes the launch cost of its few thousand small kernels from the host.
-        self.use_graphs = bool(use_graphs)
         self._graphs = {}
 
     # -- snapshots ---------------------------------------------------------------
@@ -415,8 +422,12 @@ class Trainer:
             p.grad = g
 
     # -- one iteration ----------------------------------------------------------
-    def step(self, real_img, real_c, gen_z=None):
-        """real_img: this rank's share, uint8 [n, C, H, W] (or float already in [-1, 1])."""
+    def step(self, real_img, real_c, gen_z=None, gen_c=None):
+        """real_img: this rank's share, uint8 [n, C, H, W] (or float already in [-1, 1]).  gen_z / gen_c: latents and
+        labels of the generated images, [phases * n, ...] (one run of n per phase).  The reference draws every
+        generated label from a random item of the dataset (training_loop.py:364-366); a caller with a label table
+        passes such draws as gen_c.  Without gen_c the labels of this real batch are resampled with replacement,
+        independently for every phase."""
         n_rank = self.batch_size // self.num_gpus
         with torch.autograd.profiler.record_function('data_fetch'):
             real = real_img.to(self.device)
@@ -429,7 +440,13 @@ class Trainer:
             if gen_z is None:
                 gen_z = torch.randn([len(self.phases) * n_rank, self.G.z_dim], device=self.device)
             all_gen_z = [z.split(self.batch_gpu) for z in gen_z.split(n_rank)]
-            all_gen_c = [real_c.to(self.device).split(self.batch_gpu) for _ in self.phases]
+            if gen_c is None:
+                gen_c = real_c.to(self.device)
+                if gen_c.shape[1] > 0:
+                    gen_c = gen_c[torch.randint(gen_c.shape[0], [len(self.phases) * n_rank], device=self.device)]
+                else:
+                    gen_c = gen_c.new_zeros([len(self.phases) * n_rank, 0])
+            all_gen_c = [c.split(self.batch_gpu) for c in gen_c.to(self.device).split(n_rank)]
         rounds = n_rank // self.batch_gpu
 
         for phase, phase_gen_z, phase_gen_c in zip(self.phases, all_gen_z, all_gen_c):

@@ -64,3 +64,38 @@ def test_product_ops_refuse_cpu_tensors():
         bias_act.bias_act(torch.zeros(1, 4), None)
     with pytest.raises(NotImplementedError):
         bias_act.bias_act(torch.zeros(1, 4), None, impl='ref')
+
+
+def test_tensors_beyond_32_bit_indexing_are_refused_with_a_message():
+    """The kernels index a tensor with 32 bits.  A convolution whose input or output has 2**31 or more elements (a
+    1024 x 1024 discriminator's first layer at 64 samples) is refused by name before anything is launched."""
+    from ga_gan_amd import _lib, conv2d_plugin
+    handle = _lib.lib()
+    phase = conv2d_plugin.Phase()
+    phase.nky = phase.nkx = 1
+    p = conv2d_plugin.Conv2dParams(n=64, ci=3, h=1024, w_in=1024, co=32, oh=1024, ow=1024, in_step=1, out_step=1, num_phases=1,
+                                   act=1, alpha=0.2, gain=1.0, clamp=-1.0, dtype=2)
+    p.phase[0] = phase
+    assert handle.sg_conv2d(ctypes.byref(p), None) == -1
+    assert b'too large' in handle.sg_last_error()
+    p.n = 63                                             # one sample fewer fits; the next complaint is the NULL pointers
+    assert handle.sg_conv2d(ctypes.byref(p), None) == -3
+    q = conv2d_plugin.Conv2dWgradParams(n=64, cx=3, h=1024, w_in=1024, cg=32, gh=1024, gw=1024, step=1, nky=1, nkx=1, dtype=2)
+    assert handle.sg_conv2d_wgrad(ctypes.byref(q), None) == -1
+    assert b'too large' in handle.sg_last_error()
+
+
+def test_dmain_keeps_two_passes_when_one_would_outgrow_32_bit_indexing():
+    """Both halves of Dmain share one discriminator pass only while the largest tensor of that pass stays below
+    2**31 elements: at 1024 x 1024 that holds for 16 + 16 samples and not for 32 + 32."""
+    import torch
+    from ga_gan_amd.training import loss as loss_module
+    from ga_gan_amd.training import networks
+    D = networks.Discriminator(c_dim=0, img_resolution=1024, img_channels=3, channel_base=32768, channel_max=512,
+                               epilogue_kwargs=dict(mbstd_group_size=4))
+    assert 33554432 <= D.largest_activation_elements() < 2 ** 31 // 63
+    loss = loss_module.StyleGAN2Loss(device=torch.device('cpu'), G_mapping=None, G_synthesis=None, D=D)
+    assert loss._merged_groups(16, 16) == 4
+    assert loss._merged_groups(32, 32) is None
+    small = networks.Discriminator(c_dim=0, img_resolution=64, img_channels=3, epilogue_kwargs=dict(mbstd_group_size=4))
+    assert loss_module.StyleGAN2Loss(device=torch.device('cpu'), G_mapping=None, G_synthesis=None, D=small)._merged_groups(32, 32) == 4

@@ -244,6 +244,242 @@ def test_full_size_generator_256_bf16():
     assert golden_io.rel_err(img.double().sum(dim=[0, 1, 3]), case.t('row_sums')) < 3e-2
 
 
+FULL = golden_io.load('full_size_grads')
+
+
+def fill_seeded(module, m):
+    sd = module.state_dict()
+    for name, shape in zip(m['names'], m['shapes']):
+        assert list(sd[name].shape) == shape, name
+        sd[name] = seeded_fill(name, shape)
+    module.load_state_dict(sd, strict=True)
+
+
+def check_summary(case, prefix, t, tol, crop):
+    assert golden_io.rel_err(t[:, :, crop[0]:crop[1], crop[0]:crop[1]], case.t(prefix + 'crop')) < tol, prefix + 'crop'
+    assert golden_io.rel_err(t.double().sum(dim=[0, 1, 3]), case.t(prefix + 'row_sums')) < tol, prefix + 'row_sums'
+    assert abs(float(t.double().abs().sum()) / float(case.np(prefix + 'abs_sum')) - 1) < tol, prefix + 'abs_sum'
+
+
+@pytest.mark.parametrize('num_fp16_res', [0, 4], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [c for c in FULL if c.meta['kind'] == 'G'], ids=lambda c: c.meta['tag'])
+def test_full_size_generator_gradients(case, num_fp16_res):
+    """Full-size generators (256 Affine+, 1024 AffineLight+), batch 1, training mode, on seeded parameters: image and
+    the gradient of every trainable parameter.
+
+    The image is held to 1e-3 relative L2 of the reference's (float32) and 3e-2 (bfloat16 in the four highest
+    resolutions).  The style gradients are sums of 1e5 .. 1e6 signed terms per channel that cancel to a small
+    remainder, which makes them ill-conditioned in float32: the reference's own float32 result lies 2e-4 .. 5e-3
+    (relative L2, per tensor) from the same gradient evaluated in float64 (fixture entries 'xg.'), and two CPU float32
+    evaluations of the same graph differ from each other by as much.  Each tensor is therefore compared with the
+    float64 gradient, with a tolerance of 2e-3 or three times the reference's own distance from it, whichever is
+    larger.  bfloat16 runs (activations and gradients pass through up to eight bf16 layers, twice) get 0.2 per
+    tensor, except the tensors where the reference itself is off by 2e-3 or more; all gradients taken as one vector
+    must lie within 2e-3 (float32) and 0.1 (bfloat16)."""
+    from ga_gan_amd.training import training_loop
+    m = case.meta
+    G = networks().Generator(
+        z_dim=512, c_dim=0, w_dim=512, img_resolution=m['res'], img_channels=3, mapping_kwargs=dict(num_layers=8),
+        synthesis_kwargs=dict(channel_base=m['channel_base'], channel_max=512, num_fp16_res=num_fp16_res, conv_clamp=256,
+                              use_domain_modulation=True, domain_modulation_parametrization=m['parametrization'],
+                              generator_requires_grad_parts=m['parts']))
+    fill_seeded(G, m)
+    G.to(DEV).train()
+    training_loop.set_requires_grad(G, list(m['parts']))
+    assert sorted(k for k, p in G.named_parameters() if p.requires_grad) == sorted(m['trainable'])
+    z = torch.randn(1, 512, generator=torch.Generator().manual_seed(m['z_seed'])).to(DEV)
+    img = G(z, torch.zeros(1, 0, device=DEV), noise_mode='const')
+    assert img.dtype == torch.float32
+    mid = m['res'] // 2
+    check_summary(case, 'img_', img.detach(), 1e-3 if num_fp16_res == 0 else 3e-2, (mid - 8, mid + 8))
+    dy = torch.randn(img.shape, generator=torch.Generator().manual_seed(m['dy_seed'])).to(DEV)
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad((img * dy).sum(), [params[k] for k in m['trainable']])
+    worst, num, den = {}, 0.0, 0.0
+    for k, g in zip(m['trainable'], grads):
+        whole = 'g.' + k in case
+        got = g if whole else g.flatten()[::61]
+        ref, exact = case.t(('g.' if whole else 'gs.') + k), case.t(('xg.' if whole else 'xgs.') + k)
+        ref_err = golden_io.rel_err(ref, exact)
+        err = golden_io.rel_err(got, exact)
+        num += float((got.detach().double().cpu() - exact.double()).square().sum())
+        den += float(exact.double().square().sum())
+        if num_fp16_res == 0:
+            tol = max(2e-3, 3 * ref_err)
+        else:
+            tol = 0.2 if ref_err < 2e-3 else float('inf')     # (the worst-conditioned tensors count in the total only)
+        if err >= tol:
+            worst[k] = (err, tol)
+    assert not worst, worst
+    assert (num / den) ** 0.5 < (2e-3 if num_fp16_res == 0 else 0.1)      # all trainable gradients as one vector
+
+
+@pytest.mark.parametrize('num_fp16_res', [0, 4], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [c for c in FULL if c.meta['kind'] == 'D'], ids=lambda c: c.meta['tag'])
+def test_full_size_discriminator(case, num_fp16_res):
+    """Full-size discriminators at 256 / 512 / 1024 on seeded parameters and images: logits, the image gradient of
+    their sum, every bias gradient and the norm of every weight gradient against the reference's float32 run.
+    float32: 1e-3 (relative L2; logits 1e-4 of their magnitude).  bfloat16 in the four highest resolutions: 0.1 for
+    the logits (a sum of O(1) terms that cancels to 0.06 .. 0.5 on these random weights) and 0.25 for gradients
+    (eight bf16 layers forward and back)."""
+    m = case.meta
+    D = networks().Discriminator(c_dim=0, img_resolution=m['res'], img_channels=3, channel_base=m['channel_base'],
+                                 channel_max=512, num_fp16_res=num_fp16_res, conv_clamp=256,
+                                 epilogue_kwargs=dict(mbstd_group_size=m['mbstd_group_size']))
+    fill_seeded(D, m)
+    D.to(DEV).train().requires_grad_(True)
+    n, res = m['batch'], m['res']
+    img = torch.randn(n, 3, res, res, generator=torch.Generator().manual_seed(m['img_seed'])).clamp_(-1, 1).to(DEV).requires_grad_(True)
+    logits = D(img, torch.zeros(n, 0, device=DEV))
+    tol_logits, tol = (1e-4, 1e-3) if num_fp16_res == 0 else (0.1, 0.25)
+    close(logits, case.t('logits'), tol_logits, 'logits')
+    names = [k for k, _ in D.named_parameters()]
+    grads = torch.autograd.grad(logits.sum(), [img] + list(D.parameters()))
+    mid = res // 2
+    check_summary(case, 'gimg_', grads[0].detach(), tol, (mid - 8, mid + 8))
+    for k, g in zip(names, grads[1:]):
+        if k.endswith('.bias'):
+            assert golden_io.rel_err(g, case.t('g.' + k)) < tol, k
+        else:
+            assert abs(float(g.double().norm()) / float(case.np('gnorm.' + k)) - 1) < tol, k
+
+
+STEP_SHAPES = [  # per-GPU shapes of the larger bench configurations
+    ('c3', 'stylegan2', 1024, 16, 'AFFINE_LIGHT_PLUS'),
+    ('c4', 'stylegan2', 1024, 8, 'FULL'),
+    ('c5', 'stylegan2', 512, 8, 'AFFINE_PLUS'),
+]
+
+
+@pytest.mark.parametrize('tag,cfg,res,batch_gpu,par', STEP_SHAPES, ids=[s[0] for s in STEP_SHAPES])
+def test_trainer_step_at_bench_shapes(tag, cfg, res, batch_gpu, par):
+    """Three Trainer steps (Gmain, Greg, Dmain and Dreg all fire in the first one) at the per-GPU shapes of the
+    1024 AffineLight+, 1024 full fine-tune and 512 Affine+ configurations: finite statistics, trainable generator
+    parameters and the discriminator move, frozen generator parameters do not."""
+    from ga_gan_amd.training import training_loop
+    opts = training_loop.setup_training_options(cfg=cfg, resolution=res, batch_size=batch_gpu, num_gpus=1, batch_gpu=batch_gpu,
+                                                glrate=0.02 if par != 'FULL' else None, **getattr(training_loop, par))
+    trainer = training_loop.Trainer(rank=0, random_seed=0, **opts)
+    before_G = {k: p.detach().clone() for k, p in trainer.G.named_parameters()}
+    before_D = {k: p.detach().clone() for k, p in trainer.D.named_parameters()}
+    gen = torch.Generator(device=trainer.device).manual_seed(1)
+    real, real_c = trainer.synthetic_batch(gen)
+    for _ in range(3):
+        trainer.step(real, real_c)
+    torch.cuda.synchronize()
+    moved = [k for k, p in trainer.G.named_parameters() if not torch.equal(p.detach(), before_G[k])]
+    assert moved, 'no generator parameter changed'
+    if par != 'FULL':
+        parts = getattr(training_loop, par)['generator_requires_grad_parts']
+        training_loop.set_requires_grad(trainer.G, list(parts))
+        allowed = {k for k, p in trainer.G.named_parameters() if p.requires_grad}
+        assert set(moved) <= allowed, sorted(set(moved) - allowed)[:5]
+    assert any(not torch.equal(p.detach(), before_D[k]) for k, p in trainer.D.named_parameters())
+    for k, p in list(trainer.G.named_parameters()) + list(trainer.D.named_parameters()):
+        assert bool(torch.isfinite(p).all()), k
+    del trainer
+    torch.cuda.empty_cache()
+
+
+def test_dmain_at_1024_with_32_samples_takes_two_passes():
+    """32 generated + 32 real images at 1024 x 1024 in one discriminator pass would make a first-layer tensor of 2**31
+    elements, beyond the kernels' 32-bit indexing: the loss falls back to the reference's two passes and the step
+    goes through (the one-pass form is used up to 16 + 16)."""
+    from ga_gan_amd.training import training_loop
+    opts = training_loop.setup_training_options(cfg='stylegan2', resolution=1024, batch_size=32, num_gpus=1, batch_gpu=32,
+                                                glrate=0.02, **training_loop.AFFINE_LIGHT_PLUS)
+    trainer = training_loop.Trainer(rank=0, random_seed=0, **opts)
+    assert trainer.loss._merged_groups(32, 32) is None and trainer.loss._merged_groups(16, 16) == 4
+    before = {k: p.detach().clone() for k, p in trainer.D.named_parameters()}
+    real, real_c = trainer.synthetic_batch(torch.Generator(device=trainer.device).manual_seed(1))
+    assert real.shape[0] == 32
+    trainer.step(real, real_c)
+    torch.cuda.synchronize()
+    assert any(not torch.equal(p.detach(), before[k]) for k, p in trainer.D.named_parameters())
+    for k, p in trainer.D.named_parameters():
+        assert bool(torch.isfinite(p).all()), k
+    del trainer
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('fuse', [True, False], ids=['fused', 'composed'])
+@pytest.mark.parametrize('kernel_size', [1, 3])
+def test_trainable_upsampling_conv2d_layer_gets_its_weight_gradient(kernel_size, fuse):
+    """A trainable Conv2dLayer(up=2) - the skip convolution of a generator with architecture='resnet' - takes the
+    paths that flip or transpose the prepared weight; those derived tensors must stay in the autograd graph.  Checked
+    against the same layer written with torch's transposed convolution and a depthwise blur."""
+    import torch.nn.functional as F
+    n = networks()
+    torch.manual_seed(kernel_size)
+    layer = n.Conv2dLayer(16, 8, kernel_size=kernel_size, bias=False, up=2).to(DEV)
+    x = torch.randn(2, 16, 16, 16, device=DEV, requires_grad=True)
+    dy = torch.randn(2, 8, 32, 32, device=DEV)
+    old = n.FUSE_LAYERS
+    n.FUSE_LAYERS = fuse
+    try:
+        for _ in range(2):                       # the second pass meets whatever the first one cached
+            layer.weight.grad = None
+            x.grad = None
+            y = layer(x)
+            (y * dy).sum().backward()
+            assert layer.weight.grad is not None and float(layer.weight.grad.abs().max()) > 0
+            got = (y.detach().clone(), x.grad.clone(), layer.weight.grad.clone())
+    finally:
+        n.FUSE_LAYERS = old
+    w2 = layer.weight.detach().double().requires_grad_()
+    x2 = x.detach().double().requires_grad_()
+    f1 = torch.tensor([1., 3., 3., 1.], dtype=torch.float64, device=DEV)
+    f2 = torch.outer(f1, f1)
+    f2 = (f2 / f2.sum() * 4)[None, None].repeat(8, 1, 1, 1)
+    k = kernel_size
+    if k == 1:   # 1x1: convolve, insert zeros, blur (reference conv2d_resample.py:110-114)
+        c = F.conv2d(x2, w2 * layer.weight_gain)
+        z = torch.zeros(2, 8, 32, 32, dtype=torch.float64, device=DEV)
+        z[:, :, ::2, ::2] = c
+        want = F.conv2d(F.pad(z, [2, 1, 2, 1]), f2, groups=8)
+    else:        # transposed convolution with the unflipped weight, then the blur (reference conv2d_resample.py:126-137)
+        c = F.conv_transpose2d(x2, (w2 * layer.weight_gain).transpose(0, 1), stride=2)
+        want = F.conv2d(F.pad(c, [1, 1, 1, 1]), f2, groups=8)
+    (want * dy.double()).sum().backward()
+    assert golden_io.rel_err(got[0], want) < 1e-5
+    assert golden_io.rel_err(got[1], x2.grad) < 1e-5
+    assert golden_io.rel_err(got[2], w2.grad) < 1e-5
+
+
+def test_conditional_trainer_takes_generated_labels_from_the_caller():
+    """c_dim > 0: `Trainer.step` uses the caller's gen_c (one run per phase) and, without one, resamples the real
+    batch's labels with replacement per phase (the reference draws every generated label from a random dataset item,
+    training_loop.py:364-366)."""
+    from ga_gan_amd.training import training_loop
+    opts = training_loop.setup_training_options(cfg='paper256', resolution=32, batch_size=4, c_dim=5, **training_loop.FULL)
+    for k in ('G_kwargs', 'D_kwargs'):
+        kw = opts[k].get('synthesis_kwargs', opts[k])
+        kw['channel_base'], kw['channel_max'] = 512, 32
+    trainer = training_loop.Trainer(rank=0, random_seed=0, **opts)
+    seen = []
+    original = trainer.loss.accumulate_gradients
+
+    def spy(**kw):
+        seen.append((kw['phase'], kw['gen_c'].clone(), kw['real_c'].clone()))
+        return original(**kw)
+
+    trainer.loss.accumulate_gradients = spy
+    real = torch.randint(0, 256, [4, 3, 32, 32], dtype=torch.uint8, device=DEV)
+    real_c = torch.eye(5, device=DEV)[[0, 1, 2, 3]]
+    gen_c = torch.eye(5, device=DEV)[torch.arange(16) % 5]
+    trainer.step(real, real_c, gen_c=gen_c)
+    assert [s[0] for s in seen] == ['Gmain', 'Greg', 'Dmain', 'Dreg']
+    for i, (_, g_c, r_c) in enumerate(seen):
+        assert torch.equal(g_c, gen_c[4 * i:4 * i + 4]) and torch.equal(r_c, real_c)
+    seen.clear()
+    torch.manual_seed(0)
+    trainer.batch_idx = 16
+    trainer.step(real, real_c)
+    drawn = torch.cat([s[1] for s in seen])
+    assert drawn.shape == (16, 5) and bool((drawn.sum(dim=1) == 1).all()) and float(drawn[:, 4].sum()) == 0
+    assert not all(torch.equal(s[1], real_c) for s in seen)      # (resampled, not the real batch's order)
+
+
 def test_derived_tensor_cache_follows_parameter_writes():
     """Frozen networks keep packed / cast weights between calls; an in-place write to any source parameter
     (optimizer step, load_state_dict) must invalidate them.  Checked against the same calls with the cache off,

@@ -298,3 +298,31 @@ def test_mbstd_bench_shape_vs_oracle():
     close(y, want, 1e-5)
     with pytest.raises(RuntimeError, match='divisible'):
         minibatch_std.minibatch_std(x[:6].to(DEV), 4, 1)
+
+
+def test_mbstd_keeps_the_second_order_term_for_strided_inputs_and_serves_large_groups():
+    """A non-contiguous input (channels-last storage) must give the gradients of the contiguous one, including the
+    second-order term R1 takes through the statistic; groups beyond the kernels' 64 samples (whole-batch groups of a
+    large batch) are computed as well.  Both against the CPU oracle."""
+    minibatch_std = ops()[4]
+    g = torch.Generator().manual_seed(10)
+    x0 = torch.randn([8, 16, 4, 4], generator=g)
+    dy, v = torch.randn([8, 17, 4, 4], generator=g), torch.randn([8, 16, 4, 4], generator=g)
+
+    def run(x, fn):
+        y = fn(x)
+        gx, = torch.autograd.grad((y * dy.to(x.device)).sum(), x, create_graph=True)
+        ggx, = torch.autograd.grad((gx * v.to(x.device)).sum(), x)
+        return y, gx, ggx
+
+    want = run(x0.clone().requires_grad_(True), lambda x: pointwise.minibatch_std(x, 4, 1))
+    strided = x0.to(DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    assert not strided.is_contiguous()
+    got = run(strided, lambda x: minibatch_std.minibatch_std(x, 4, 1))
+    for a, b in zip(got, want):
+        close(a, b, 2e-5)
+    assert float(want[2].abs().max()) > 0
+
+    big = torch.randn([128, 8, 4, 4], generator=g)
+    want = pointwise.minibatch_std(big, None, 1)
+    close(minibatch_std.minibatch_std(big.to(DEV), None, 1), want, 1e-5)

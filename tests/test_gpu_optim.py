@@ -99,3 +99,28 @@ def test_updates_advance_tensor_versions():
     before = e._version
     optim_plugin.ema_([e], [p.detach()], 0.9)
     assert e._version > before
+
+
+def test_loaded_step_counts_stay_on_the_host(tmp_path):
+    """A snapshot read with map_location=<device> carries the step counts as device tensors; after load_state_dict
+    they live on the host again, so a step issues no device-to-host read (checked with torch's sync debug mode)."""
+    from ga_gan_amd import optim_plugin
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(17, 3, device=DEV)), torch.nn.Parameter(torch.randn(5, device=DEV))]
+    opt = optim_plugin.FusedAdam(params, lr=0.01, betas=(0.5, 0.9))
+    for p in params:
+        p.grad = torch.randn_like(p)
+    opt.step()
+    torch.save(opt.state_dict(), tmp_path / 'opt.pt')
+    loaded = torch.load(tmp_path / 'opt.pt', map_location=DEV, weights_only=True)
+    assert loaded['state'][0]['step'].is_cuda
+    fresh = optim_plugin.FusedAdam(params, lr=0.01, betas=(0.5, 0.9))
+    fresh.load_state_dict(loaded)
+    assert all(fresh.state[p]['step'].device.type == 'cpu' and int(fresh.state[p]['step']) == 1 for p in params)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        fresh.step()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert all(int(fresh.state[p]['step']) == 2 for p in params)

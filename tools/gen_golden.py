@@ -630,10 +630,124 @@ def gen_full_size():
     b.save()
 
 
+def _fill_all(module):
+    """`seeded_fill` into every parameter / buffer that the state dict carries a value for; returns the names."""
+    names = []
+    with torch.no_grad():
+        for name, t in list(module.named_parameters()) + list(module.named_buffers()):
+            if name.endswith('resample_filter') or name.endswith('ones_weights') or name.endswith('offset_mask'):
+                continue
+            t.copy_(seeded_fill(name, t.shape))
+            names.append(name)
+    return names
+
+
+def _shapes(module, names):
+    every = dict(list(module.named_parameters()) + list(module.named_buffers()))
+    return [list(every[n].shape) for n in names]
+
+
+def _summary(prefix, t, crop=None):
+    """What the fixtures keep of a large tensor: a crop, the sums over everything but the rows, and two checksums."""
+    t = t.detach()
+    out = {prefix + 'sum': t.double().sum(), prefix + 'abs_sum': t.double().abs().sum(),
+           prefix + 'row_sums': t.double().sum(dim=[0, 1, 3])}
+    if crop is not None:
+        out[prefix + 'crop'] = t[:, :, crop[0]:crop[1], crop[0]:crop[1]]
+    return out
+
+
+def _grad_entries(name, grad):
+    """A gradient whole when it is small, else every 61st element of it plus its L2 norm."""
+    if grad.numel() <= 65536:
+        return {'g.' + name: grad}
+    return {'gs.' + name: grad.flatten()[::61], 'gnorm.' + name: grad.double().norm()}
+
+
+def _exact_generator_gradients(G, names, trainable, z, dy, res, channel_base, par):
+    """The same gradients in float64, from the functional restatement of the networks under oracle/ (the reference's
+    blocks cast to float32 themselves, networks.py:1031-1034, so it cannot run in float64).  Sums of 1e5 and more
+    signed terms that nearly cancel make these gradients ill-conditioned in float32: the distance of the reference's
+    own float32 result from the float64 one is what the tests scale their tolerance with."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import stylegan2 as osg
+    every = dict(list(G.named_parameters()) + list(G.named_buffers()))
+    p = {n: every[n].detach().double() for n in names}
+    for k in trainable:
+        p[k].requires_grad_()
+    cfg = osg.GeneratorConfig(img_resolution=res, channel_base=channel_base, conv_clamp=256, use_domain_modulation=True,
+                              domain_modulation_parametrization=par)
+    img = osg.generator(p, z.double(), torch.zeros(1, 0, dtype=torch.float64), cfg, noise_mode='const')
+    return [g.float() for g in torch.autograd.grad((img * dy.double()).sum(), [p[k] for k in trainable])]
+
+
+def gen_full_size_grads():
+    """Full-size networks in float32 on seeded parameters and seeded inputs (the tests rebuild both):
+    * generators at 256 (Affine+) and 1024 (AffineLight+), batch 1, training mode: image summary and the gradient of
+      sum(img * dy) with respect to every trainable parameter (large ones as a strided sample plus their norm), from
+      the reference in float32 ('g.' / 'gs.') and in float64 arithmetic ('xg.' / 'xgs.');
+    * discriminators at 256 / 512 / 1024: logits, a summary of the image gradient of sum(logits), every bias gradient
+      and the L2 norm of every weight gradient."""
+    b = Bundle('full_size_grads')
+    gcases = [('G256_affine_plus', 256, 16384, 'out_in_additive',
+               ['synt_affine', 'tRGB_affine', 'synt_weights_offset.b64', 'tRGB_weights_offset.b64'], 5),
+              ('G1024_affine_light', 1024, 32768, 'out_in_additive,affine_out_in_5_1_additive',
+               ['synt_affine_weights_offset', 'tRGB_affine_weights_offset', 'synt_weights_offset.b64',
+                'tRGB_weights_offset.b64'], 6)]
+    for tag, res, channel_base, par, parts, z_seed in gcases:
+        torch.manual_seed(0)
+        with quiet():
+            G = ref_networks.Generator(
+                z_dim=512, c_dim=0, w_dim=512, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=8),
+                synthesis_kwargs=dict(channel_base=channel_base, channel_max=512, num_fp16_res=0, conv_clamp=256,
+                                      use_domain_modulation=True, domain_modulation_parametrization=par,
+                                      generator_requires_grad_parts=parts))
+        names = _fill_all(G)
+        G.train()
+        ref_training_loop.set_requires_grad(G, list(parts))
+        trainable = [n for n, p in G.named_parameters() if p.requires_grad]
+        z = torch.randn(1, 512, generator=torch.Generator().manual_seed(z_seed))
+        img = G(z, torch.zeros(1, 0), noise_mode='const')
+        dy = torch.randn(img.shape, generator=torch.Generator().manual_seed(z_seed + 100))
+        grads = torch.autograd.grad((img * dy).sum(), [p for p in G.parameters() if p.requires_grad])
+        mid = res // 2
+        exact = _exact_generator_gradients(G, names, trainable, z, dy, res, channel_base, par)
+        b.add(dict(tag=tag, kind='G', res=res, channel_base=channel_base, parametrization=par, parts=parts, names=names,
+                   shapes=_shapes(G, names), trainable=trainable, z_seed=z_seed, dy_seed=z_seed + 100),
+              **_summary('img_', img, (mid - 8, mid + 8)),
+              **{k: v for n, gr in zip(trainable, grads) for k, v in _grad_entries(n, gr).items()},
+              **{'x' + k: v for n, gr in zip(trainable, exact) for k, v in _grad_entries(n, gr).items() if not k.startswith('gnorm.')})
+        print(tag, 'trainable tensors', len(trainable), 'elements', sum(int(gr.numel()) for gr in grads), flush=True)
+        del G, img, grads
+
+    for tag, res, channel_base, mbstd, n, seed in [('D256', 256, 16384, 8, 4, 21), ('D512', 512, 32768, 8, 2, 22),
+                                                   ('D1024', 1024, 32768, 4, 2, 23)]:
+        torch.manual_seed(0)
+        with quiet():
+            D = ref_networks.Discriminator(c_dim=0, img_resolution=res, img_channels=3, channel_base=channel_base,
+                                           channel_max=512, num_fp16_res=0, conv_clamp=256,
+                                           epilogue_kwargs=dict(mbstd_group_size=mbstd))
+        names = _fill_all(D)
+        D.train().requires_grad_(True)
+        img = torch.randn(n, 3, res, res, generator=torch.Generator().manual_seed(seed)).clamp_(-1, 1).requires_grad_(True)
+        logits = D(img, torch.zeros(n, 0))
+        pnames = [k for k, _ in D.named_parameters()]
+        grads = torch.autograd.grad(logits.sum(), [img] + list(D.parameters()))
+        gb = {'g.' + k: gr for k, gr in zip(pnames, grads[1:]) if k.endswith('.bias')}
+        gn = {'gnorm.' + k: gr.double().norm() for k, gr in zip(pnames, grads[1:]) if not k.endswith('.bias')}
+        mid = res // 2
+        b.add(dict(tag=tag, kind='D', res=res, channel_base=channel_base, mbstd_group_size=mbstd, batch=n, img_seed=seed,
+                   names=names, shapes=_shapes(D, names)),
+              logits=logits, **_summary('gimg_', grads[0], (mid - 8, mid + 8)), **gb, **gn)
+        print(tag, 'logits', logits.flatten().tolist(), flush=True)
+        del D, img, grads
+    b.save()
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv2d_resample', 'modulated_conv2d', 'misc_ops', 'grid_sample', 'augment', 'data_path', 'layers',
-                             'networks', 'loss', 'full_size']
+                             'networks', 'loss', 'full_size', 'full_size_grads']
     for name in which:
         globals()['gen_' + name]()
