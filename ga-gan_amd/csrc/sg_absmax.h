@@ -1,0 +1,40 @@
+// Largest magnitudes of float tensors, measured on the device in front of the kernels that multiply float
+// operands as pairs of halves (sg_conv2d.hip, sg_wgrad_f32.hip): a half holds magnitudes up to 65504, so every
+// operand is first multiplied by the power of two that brings its tensor's largest magnitude to 2^14 .. 2^15,
+// and the accumulators are multiplied by the inverse afterwards (exact both ways).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sg {
+
+// Measures max |a|, max |b|, max |c|, max |d| (absent tensors: n = 0) into four words of a slot of a fixed
+// ring of slots in device memory and returns the slot in *slot; the words hold the float bit patterns (0 for an absent or
+// all-zero tensor).  Two small launches on `stream`; nothing is allocated and the host does not wait.  The ring
+// has 512 slots per device: a slot is written again 512 calls later, long after the kernel that read it has
+// finished on any one stream (work recorded into a HIP graph keeps the slots it was recorded with).
+int absmax_measure(hipStream_t stream, const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc,
+                   const float* d, int64_t nd, const unsigned** slot);
+
+// The power of two `mul` with amax * mul in [2^14, 2^15) and its inverse; both 1 when amax is zero, denormal or
+// not finite (non-finite operands poison the result either way).
+__device__ __forceinline__ void half_range_scale(float amax, float& mul, float& inv) {
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u);
+    int shift = (e == 0 || e == 255) ? 0 : 141 - e;
+    shift = shift > 126 ? 126 : (shift < -126 ? -126 : shift);
+    mul = __builtin_bit_cast(float, (unsigned)(127 + shift) << 23);
+    inv = __builtin_bit_cast(float, (unsigned)(127 - shift) << 23);
+}
+
+// Scales of an operand tensor (word `tensor_word`) that is multiplied by a per-channel scale (word `scale_word`,
+// ignored when `has_scale` is false) while it is staged.
+__device__ __forceinline__ void half_range_scale(const unsigned* slot, int tensor_word, int scale_word, bool has_scale, float& mul,
+                                                 float& inv) {
+    float amax = __builtin_bit_cast(float, slot[tensor_word]);
+    if (has_scale) amax *= __builtin_bit_cast(float, slot[scale_word]);
+    half_range_scale(amax, mul, inv);
+}
+
+}  // namespace sg

@@ -18,20 +18,20 @@
 //   * the weight chunk [tap][BM][channel-chunk] is copied to LDS with 16-byte accesses
 //     from the pre-packed weight tensor [phase][ky][kx][co][ci];
 //   * every wave then issues, per tap, BM/16 A reads + 4 B reads and BM/16 x 4 MFMAs
-//     (v_mfma_f32_16x16x32 for 16-bit types, 4 x v_mfma_f32_16x16x4_f32 for float).
+//     (v_mfma_f32_16x16x32 for 16-bit types).
 // Pixel rows are padded to 80 bytes in LDS so that the 16 lanes of a read group fall
 // on different 16-byte bank slots.  Accumulation is float; the epilogue runs on the
 // accumulators and stores once.
 //
-// float32 tensors run on the bf16 matrix instruction as well: a float is the exact sum of
-// three bf16 values (its 24 significant bits cut into three runs of 8), both operands are
-// staged to LDS as three such planes, and a product is accumulated from the six partial
-// products whose weight is at least 2^-16 of the leading one (a0 b0, a0 b1, a1 b0, a0 b2,
-// a1 b1, a2 b0; every one of them exact in the float accumulator's input, the three dropped
-// ones are below 2^-23 of the product, i.e. below float rounding).  Six 16x16x32 bf16
-// instructions take 96 cycles per 32 channels where eight 16x16x4 float ones take 256.  A
-// chunk is 32 channels (3 x 64 bytes per pixel row, pitch 208); the weight chunk is staged
-// three taps at a time so that the tile fits LDS.
+// float32 tensors run on the half-precision matrix instruction as well: each operand tensor is multiplied by the
+// power of two that brings its largest magnitude (measured on the device in front of the kernel, sg_absmax.h)
+// to 2^14 .. 2^15, every element is cut into two halves h0 + h1 that carry 22 of its 24 significant bits, both
+// operands are staged to LDS as two such planes, and a product is accumulated from the three partial products
+// h0 h0', h0 h1', h1 h0' (what is dropped lies below 2^-21 of the product; measured against float64 the layers
+// stay at the 1e-6 relative error of a float32 evaluation).  Three 16x16x32 instructions take 48 cycles per 32
+// channels where eight 16x16x4 float ones take 256.  A chunk is 32 channels (2 x 64 bytes per pixel row, pitch
+// 144); the weight chunk is staged three taps at a time so that the tile fits LDS.
+#include "sg_absmax.h"
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
@@ -49,7 +49,7 @@ constexpr int kPitch = 80;        // bytes per LDS pixel row: 64 payload + 16 pa
 constexpr int kChunkBytes = 64;   // K payload per pixel per chunk
 constexpr int kPixels = 256;      // output pixels per workgroup
 constexpr int kThreads = 256;
-constexpr int kPitchSplit = 208;  // bytes per LDS pixel row of a float tensor split into 3 bf16 planes: 3 x 64 + 16 pad
+constexpr int kPitchSplit = 144;  // bytes per LDS pixel row of a float tensor split into 2 half planes: 2 x 64 + 16 pad
 constexpr int kSplitTaps = 3;     // taps of the weight chunk held in LDS at a time (split float path)
 
 __device__ __forceinline__ int floor_div_i(int a, int b);
@@ -66,41 +66,40 @@ template <> struct Mma<__half> {
     }
 };
 
-// Two floats a, b -> three dwords p0, p1, p2 of bf16 pairs (a's piece in the low half) with
-// a = a0 + a1 + a2 and b = b0 + b1 + b2 exactly: each piece is the leading 8 significant bits (the upper
-// 16 bits of the float pattern) of what the previous pieces left.  Eleven vector operations per pair.  A
-// non-finite input leaves NaN in the lower pieces (inf - inf), so it poisons the outputs it reaches.
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    constexpr unsigned kUpperHalves = 0x07060302u;   // v_perm_b32: {b[31:16], a[31:16]}
-    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
-    p0 = __builtin_amdgcn_perm(ub, ua, kUpperHalves);
-    const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u), rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
-    const unsigned va = __builtin_bit_cast(unsigned, ra), vb = __builtin_bit_cast(unsigned, rb);
-    p1 = __builtin_amdgcn_perm(vb, va, kUpperHalves);
-    const float sa = ra - __builtin_bit_cast(float, va & 0xffff0000u), sb = rb - __builtin_bit_cast(float, vb & 0xffff0000u);
-    p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), kUpperHalves);
+// The float path multiplies in half precision without giving up float accuracy: every operand element v (times a
+// power of two that brings the tensor's largest magnitude to 2^14 .. 2^15, see sg_absmax.h) is cut into
+// v = h0 + h1 + e with h0 = half(v), h1 = half(v - h0), both rounded to nearest, so |e| <= 2^-22 |v| (an element
+// more than 2^17 below the tensor's maximum keeps an absolute error of 2^-40 of that maximum instead); the
+// products h0 h0', h0 h1' and h1 h0' are accumulated in float by the matrix instructions, and what is dropped,
+// h1 h1', is below 2^-22 of the product as well.  A non-finite input poisons the outputs it reaches.
+__device__ __forceinline__ unsigned pack_halves(_Float16 lo, _Float16 hi) {
+    return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
 }
 
-// One float -> its three bf16 bit patterns (the scalar staging path).
-__device__ __forceinline__ void split3(float v, unsigned& h0, unsigned& h1, unsigned& h2) {
-    unsigned p0, p1, p2;
-    split3_pair(v, 0.f, p0, p1, p2);
-    h0 = p0 & 0xffffu; h1 = p1 & 0xffffu; h2 = p2 & 0xffffu;
+// Two floats a, b -> two dwords p0, p1 of half pairs (a's piece in the low half).
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned& p0, unsigned& p1) {
+    const _Float16 a0 = (_Float16)a, b0 = (_Float16)b;
+    p0 = pack_halves(a0, b0);
+    p1 = pack_halves((_Float16)(a - (float)a0), (_Float16)(b - (float)b0));
 }
 
-// The six partial products of the split float path, smallest first.
-__device__ __forceinline__ void mma_split(const uint4 (&a)[3], const uint4 (&b)[3], f32x4_t& c) {
-    using M = Mma<__hip_bfloat16>;
-    M::run(a[2], b[0], c);
-    M::run(a[1], b[1], c);
-    M::run(a[0], b[2], c);
+// One float -> its two half bit patterns (the scalar staging path).
+__device__ __forceinline__ void split2(float v, unsigned& h0, unsigned& h1) {
+    const _Float16 v0 = (_Float16)v;
+    h0 = __builtin_bit_cast(unsigned short, v0);
+    h1 = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)v0));
+}
+
+// The three partial products of the split float path, smallest first.
+__device__ __forceinline__ void mma_split(const uint4 (&a)[2], const uint4 (&b)[2], f32x4_t& c) {
+    using M = Mma<__half>;
     M::run(a[1], b[0], c);
     M::run(a[0], b[1], c);
     M::run(a[0], b[0], c);
 }
 
-// Split-float form of stage_pixels / stage_pixels_vec: the footprint of 32 channels from c0 on, as three bf16
-// planes per pixel row (plane p at byte p * 64, channel c at 2 c).  An item is one channel pair x VEC
+// Split-float form of stage_pixels / stage_pixels_vec: the footprint of 32 channels from c0 on, as two half
+// planes per pixel row (plane p at byte p * 64, channel c at 2 c), every value times the power of two `mul`.  An item is one channel pair x VEC
 // consecutive pixels of a row (VEC = 4: one aligned 16-byte packet per channel; VEC = 1: any row length).  The
 // copy is cut into a load half (global memory -> registers, with the two channel scales) and a store half
 // (scale, split, LDS) so that a caller can keep the loads of the next chunk in flight behind its multiplies.
@@ -109,12 +108,13 @@ struct SplitGeom {
     const float* scale;
     int n_total, c_total, h, w, img0, imgs, iy0, ix0, lh, lw;
     int vx0, nv, items;
+    float mul;
 };
 
 template <int VEC>
 __device__ __forceinline__ SplitGeom split_geom(const float* x, const float* scale, int n_total, int c_total, int h, int w,
-                                                int img0, int imgs, int iy0, int ix0, int lh, int lw) {
-    SplitGeom g{x, scale, n_total, c_total, h, w, img0, imgs, iy0, ix0, lh, lw, 0, 0, 0};
+                                                int img0, int imgs, int iy0, int ix0, int lh, int lw, float mul) {
+    SplitGeom g{x, scale, n_total, c_total, h, w, img0, imgs, iy0, ix0, lh, lw, 0, 0, 0, mul};
     g.vx0 = floor_div_i(ix0, VEC);
     g.nv = floor_div_i(ix0 + lw - 1, VEC) - g.vx0 + 1;
     g.items = imgs * lh * g.nv * 16;
@@ -130,7 +130,7 @@ template <int VEC>
 __device__ __forceinline__ void split_item_load(const SplitGeom& g, int c0, int it, SplitItem<VEC>& d) {
 #pragma unroll
     for (int j = 0; j < VEC; j++) d.va[j] = d.vb[j] = 0.f;
-    d.s0 = d.s1 = 1.f;
+    d.s0 = d.s1 = g.mul;
     if (it >= g.items) return;
     const int cg = it & 15;
     int r = it >> 4;
@@ -155,8 +155,8 @@ __device__ __forceinline__ void split_item_load(const SplitGeom& g, int c0, int 
         if (two) d.vb[0] = src[plane];
     }
     if (g.scale) {
-        d.s0 = g.scale[(int64_t)n * g.c_total + c];
-        d.s1 = two ? g.scale[(int64_t)n * g.c_total + c + 1] : 0.f;
+        d.s0 = g.scale[(int64_t)n * g.c_total + c] * g.mul;
+        d.s1 = two ? g.scale[(int64_t)n * g.c_total + c + 1] * g.mul : 0.f;
     }
 }
 
@@ -172,12 +172,11 @@ __device__ __forceinline__ void split_item_store(unsigned char* s_dst, const Spl
     for (int j = 0; j < VEC; j++) {
         const int rx = rx0 + j;
         if (rx < 0 || rx >= g.lw) continue;
-        unsigned p0, p1, p2;
-        split3_pair(d.va[j] * d.s0, d.vb[j] * d.s1, p0, p1, p2);
+        unsigned p0, p1;
+        split2_pair(d.va[j] * d.s0, d.vb[j] * d.s1, p0, p1);
         unsigned char* dst = row + rx * kPitchSplit;
         *reinterpret_cast<unsigned*>(dst) = p0;
         *reinterpret_cast<unsigned*>(dst + 64) = p1;
-        *reinterpret_cast<unsigned*>(dst + 128) = p2;
     }
 }
 
@@ -193,13 +192,13 @@ __device__ __forceinline__ void stage_pixels_split(unsigned char* s_dst, const S
     }
 }
 
-// Four consecutive channels of one weight row -> the three bf16 planes of the LDS row (8 bytes each).
-__device__ __forceinline__ void split_weight_store(unsigned char* dst, const float4& v) {
-    unsigned lo[3], hi[3];
-    split3_pair(v.x, v.y, lo[0], lo[1], lo[2]);
-    split3_pair(v.z, v.w, hi[0], hi[1], hi[2]);
+// Four consecutive channels of one weight row (times `mul`) -> the two half planes of the LDS row (8 bytes each).
+__device__ __forceinline__ void split_weight_store(unsigned char* dst, const float4& v, float mul) {
+    unsigned lo[2], hi[2];
+    split2_pair(v.x * mul, v.y * mul, lo[0], lo[1]);
+    split2_pair(v.z * mul, v.w * mul, hi[0], hi[1]);
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) *reinterpret_cast<uint2*>(dst + pl * 64) = make_uint2(lo[pl], hi[pl]);
+    for (int pl = 0; pl < 2; pl++) *reinterpret_cast<uint2*>(dst + pl * 64) = make_uint2(lo[pl], hi[pl]);
 }
 
 struct Tile {
@@ -208,6 +207,7 @@ struct Tile {
     int lw, lh;           // LDS footprint of one image's tile (pixels)
     int tiles_a, tiles_b, tiles_img;
     int vec_epi;          // epilogue through LDS with 16-byte global accesses (8 pixels of one channel per lane)
+    const unsigned* amax; // float path: largest magnitudes of x, w and in_scale (bit patterns), see sg_absmax.h
 };
 
 // Pixel slot (0..255) of a workgroup -> column, row and image within its tile; ri >= t.imgs marks an idle slot.
@@ -367,7 +367,7 @@ template <class T> constexpr int conv_threads() { return sizeof(T) == 4 ? 512 : 
 template <class T, int M_TILES>
 __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) conv2d_mfma_kernel(sg_conv2d_params p, Tile t) {
     using S = float;
-    constexpr bool SPLIT = sizeof(T) == 4;              // float: three bf16 planes per operand
+    constexpr bool SPLIT = sizeof(T) == 4;              // float: two half planes per operand
     constexpr int THREADS = conv_threads<T>(), WAVES = THREADS / 64;
     constexpr int NT = kPixels / (16 * WAVES);          // 16-pixel n-tiles per wave: 4 or 2
     constexpr int WPX = 16 * NT;                        // pixel slots per wave
@@ -421,23 +421,30 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
 
     const bool w_vec = (p.ci % (16 / (int)sizeof(T)) == 0);
 
+    // float path: the powers of two that bring both operands into the range of a half, and their inverses
+    float mul_x = 1.f, inv_x = 1.f, mul_w = 1.f, inv_w = 1.f;
+    if constexpr (SPLIT) {
+        half_range_scale(t.amax, 0, 2, p.in_scale != nullptr, mul_x, inv_x);
+        half_range_scale(t.amax, 1, 3, false, mul_w, inv_w);
+    }
+
     // ---- split float path: multiply the staged taps [g0, g0 + gtaps) of the weight chunk ------------------------
     auto split_multiply = [&](int g0, int gtaps) {
         for (int tl = 0; tl < gtaps; tl++) {
             const int tap = g0 + tl;
             const int ky = tap / ph.nkx, kx = tap - ky * ph.nkx;
-            uint4 a[M_TILES][3];
+            uint4 a[M_TILES][2];
 #pragma unroll
             for (int m = 0; m < M_TILES; m++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
+                for (int pl = 0; pl < 2; pl++)
                     a[m][pl] = *reinterpret_cast<const uint4*>(s_w + (tl * BM + m * 16) * PITCH + pl * 64 + a_addr);
             const int tap_off = (ky * lw + kx) * PITCH;
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                uint4 b[3];
+                uint4 b[2];
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) b[pl] = *reinterpret_cast<const uint4*>(s_in + b_addr[j] + tap_off + pl * 64);
+                for (int pl = 0; pl < 2; pl++) b[pl] = *reinterpret_cast<const uint4*>(s_in + b_addr[j] + tap_off + pl * 64);
 #pragma unroll
                 for (int m = 0; m < M_TILES; m++) {
                     mma_split(a[m], b, acc[m][j]);
@@ -457,7 +464,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         if (fast) {
             constexpr int W_IT = (kSplitTaps * BM * 8 + THREADS - 1) / THREADS;   // packets of 4 channels per lane
             constexpr int X_IT = 2048 / THREADS;                                                 // input items per lane held in registers
-            const SplitGeom g = split_geom<4>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw);
+            const SplitGeom g = split_geom<4>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw, mul_x);
             const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
             const int c_begin = ksplit * chunks_per_split * KCH;
             const int c_end = min(p.ci, c_begin + chunks_per_split * KCH);
@@ -481,7 +488,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
 #pragma unroll
                 for (int k = 0; k < W_IT; k++) {
                     const int e = tid + k * THREADS;
-                    if (e < gtaps * BM * 8) split_weight_store(s_w + (e >> 3) * PITCH + (e & 7) * 8, wreg[k]);
+                    if (e < gtaps * BM * 8) split_weight_store(s_w + (e >> 3) * PITCH + (e & 7) * 8, wreg[k], mul_w);
                 }
             };
             auto x_load = [&](int c0) {
@@ -524,7 +531,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         __syncthreads();   // everyone is done reading the previous chunk
         if constexpr (SPLIT) {
             // (slow form of the split path: rows that are no whole packets, or channel counts that are no multiple of 4)
-            const SplitGeom g = split_geom<1>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw);
+            const SplitGeom g = split_geom<1>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw, mul_x);
             stage_pixels_split<1, THREADS>(s_in, g, c0, 0);
             for (int g0 = 0; g0 < taps; g0 += kSplitTaps) {
                 const int gtaps = min(kSplitTaps, taps - g0);
@@ -534,10 +541,10 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
                     const int o = row % BM, tap = g0 + row / BM;
                     float v = 0.f;
                     if (m0 + o < p.co && c0 + cc < p.ci) v = w[((int64_t)tap * p.co + m0 + o) * p.ci + c0 + cc];
-                    unsigned h0, h1, h2;
-                    split3(v, h0, h1, h2);
+                    unsigned h0, h1;
+                    split2(v * mul_w, h0, h1);
                     unsigned short* dst = reinterpret_cast<unsigned short*>(s_w + row * PITCH + cc * 2);
-                    dst[0] = (unsigned short)h0; dst[32] = (unsigned short)h1; dst[64] = (unsigned short)h2;
+                    dst[0] = (unsigned short)h0; dst[32] = (unsigned short)h1;
                 }
                 __syncthreads();
                 split_multiply(g0, gtaps);
@@ -586,6 +593,13 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             }
         }
         }   // !SPLIT
+    }
+
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int m = 0; m < M_TILES; m++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[m][j] = acc[m][j] * inv_x * inv_w;
     }
 
     // ---- epilogue, wide form: the accumulators go through LDS as [pixel][channel] floats and come back as
@@ -806,7 +820,7 @@ Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     while (!exact && t.th > 1 && t.th / 2 >= AH) t.th /= 2;
     t.lw = (t.tw - 1) * p.in_step + max_nkx;
     if (split) {
-        // Rows of 208 bytes: pick the rows x images per tile that fill the most pixel slots within the LDS budget
+        // Rows of 144 bytes: pick the rows x images per tile that fill the most pixel slots within the LDS budget
         // (slots beyond imgs * th * tw idle).  Tiles that feed the per-image reduction keep whole 16-pixel groups.
         const size_t budget = 152 * 1024 / pitch - (size_t)min(max_taps, kSplitTaps) * 64;
         int best_th = 1, best_imgs = 1, best_used = 0;
@@ -878,6 +892,15 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
                 p.ow % 8 == 0 && t.tw % 8 == 0 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
                 (!p.reduce_out || aligned16(p.reduce_x));
     if (t.vec_epi) lds = std::max(lds, (size_t)kPixels * (BM + 4) * sizeof(float));
+    t.amax = nullptr;
+    if constexpr (SPLIT) {
+        int64_t w_elems = 0;
+        for (int i = 0; i < p.num_phases; i++)
+            w_elems = std::max<int64_t>(w_elems, p.phase[i].w_offset + (int64_t)p.phase[i].nky * p.phase[i].nkx * p.co * p.ci);
+        if (int rc = absmax_measure(stream, (const float*)p.x, (int64_t)p.n * p.ci * p.h * p.w_in, (const float*)p.w, w_elems,
+                                    p.in_scale, (int64_t)p.n * p.ci, nullptr, 0, &t.amax))
+            return rc;
+    }
     dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)(p.num_phases * t.split_k));
     auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
     if (lds > 64 * 1024) {   // opt in to large dynamic LDS (idempotent, cheap)

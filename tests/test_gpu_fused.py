@@ -140,3 +140,54 @@ def test_conv2d_style_reduction_rows():
         ref = torch.nn.functional.conv2d(x.cpu().double(), w.cpu().double(), padding=1)
         assert _rel(y.cpu(), ref) < 1e-5
         assert _rel(red.cpu(), (ref * r.cpu().double()).sum(dim=[2, 3])) < 1e-5
+
+
+F64_CASES = [
+    # n, ci, co, res, k, up, magnitude of x, magnitude of dy
+    (1, 512, 512, 16, 3, 1, 1.0, 1.0),
+    (1, 512, 512, 16, 3, 2, 1.0, 1.0),
+    (1, 512, 3, 32, 1, 1, 1.0, 1.0),
+    (4, 256, 256, 64, 3, 1, 1.0, 1.0),
+    (2, 128, 128, 32, 3, 1, 3e4, 1e-9),      # activations near the top of a half's range, gradients far below it
+    (2, 64, 96, 32, 3, 1, 1e-7, 1e5),
+    (2, 36, 40, 12, 3, 1, 1.0, 1.0),         # ragged: the scalar staging path
+]
+
+
+@pytest.mark.parametrize('case', F64_CASES, ids=[f'f{i}' for i in range(len(F64_CASES))])
+def test_float32_layers_against_float64(case):
+    """The float32 kernels multiply in half precision pieces after scaling each operand tensor into a half's range:
+    values and every gradient of wide low-resolution layers stay within 5e-6 relative L2 of the same layer in
+    float64 arithmetic (a float32 evaluation lies at 1e-6), whatever the magnitude of activations and gradients."""
+    import torch.nn.functional as F
+    from ga_gan_amd.torch_utils.ops import fused_layer, upfirdn2d
+    n, ci, co, res, k, up, mag_x, mag_dy = case
+    g = torch.Generator().manual_seed(res + ci)
+    x = torch.randn(n, ci, res, res, generator=g) * mag_x
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    s = 1 + 0.3 * torch.randn(n, ci, generator=g)
+    d = 1 + 0.3 * torch.rand(n, co, generator=g)
+    b = 0.1 * torch.randn(co, generator=g) * mag_x
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device='cuda')
+    leaves = [t.cuda().requires_grad_() for t in (x, w, s, d, b)]
+    y = fused_layer.conv_layer(leaves[0], leaves[1], f=f, up=up, down=1, padding=k // 2, flip_weight=(up == 1), styles=leaves[2],
+                               dcoefs=leaves[3], bias=leaves[4], act='lrelu' if k == 3 else 'linear', clamp=None)
+    dy = torch.randn(y.shape, generator=g) * mag_dy
+    y.backward(dy.cuda())
+    exact = [t.double().requires_grad_() for t in (x, w, s, d, b)]
+    xm = exact[0] * exact[2].reshape(n, ci, 1, 1)
+    if up == 1:
+        c = F.conv2d(xm, exact[1], padding=k // 2)
+    else:
+        c = F.conv_transpose2d(xm, exact[1].transpose(0, 1), stride=2)
+        f1 = torch.tensor([1., 3, 3, 1], dtype=torch.float64)
+        f2 = torch.outer(f1, f1)
+        f2 = f2 / f2.sum() * 4
+        c = F.conv2d(F.pad(c, [1, 1, 1, 1]).reshape(n * co, 1, c.shape[2] + 2, c.shape[3] + 2), f2[None, None]).reshape(n, co, 2 * res, 2 * res)
+    c = c * exact[3].reshape(n, co, 1, 1) + exact[4].reshape(1, co, 1, 1)
+    if k == 3:
+        c = F.leaky_relu(c, 0.2) * 2 ** 0.5
+    c.backward(dy.double())
+    assert _rel(y.detach().cpu(), c.detach()) < 5e-6
+    for name, a, e in zip('x w styles dcoefs bias'.split(), leaves, exact):
+        assert _rel(a.grad.cpu(), e.grad) < 5e-6, (name, _rel(a.grad.cpu(), e.grad))
