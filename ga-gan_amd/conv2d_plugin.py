@@ -27,7 +27,20 @@ class Conv2dParams(ctypes.Structure):
                 ('phase', Phase * 4),
                 ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
                 ('reduce_x', ctypes.c_void_p), ('reduce_out', ctypes.c_void_p),
-                ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float)]
+                ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+
+
+def _attach_workspace(p, query, like):
+    """Scratch memory for the float32 kernels, from torch's allocator (stream-ordered, and inside a graph capture it
+    comes from the graph's own pool: the library's fallback buffer would have to grow with hipMalloc there).  The
+    tensor is returned so that it outlives the launch."""
+    need = int(query(ctypes.byref(p)))
+    if need == 0:
+        return None
+    work = torch.empty([need], dtype=torch.uint8, device=like.device)
+    p.workspace, p.workspace_bytes = work.data_ptr(), need
+    return work
 
 
 class Plan:
@@ -117,14 +130,16 @@ REDUCED_MAX_PARTIALS = 1 << 20   # SG_CONV2D_REDUCED_MAX_PARTIALS of include/sg_
 
 def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
            act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None, reduce_x=None, out=None, reduce_sum=None,
-           mask_y=None, mask_alpha=1.0, mask_clamp=-1.0):
+           mask_y=None, mask_alpha=1.0, mask_clamp=-1.0, workspace=None):
     """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow].
     `out_hw` overrides the plan's natural output size (pixels whose taps all fall outside x are zero).
     With `reduce_x` (y's shape and dtype) the call returns (y, r), r[n, co] = sum over pixels of
     reduce_x * (the contraction before out_scale and the epilogue), float32.
     With `out` (and, for a reduction, `reduce_sum` [n, co] float32) given, the results are written there and the
     call allocates no device memory: the reduction then runs through `sg_conv2d_reduced`, whose partial sums live
-    in a fixed array inside the library (at most REDUCED_MAX_PARTIALS of them, one call at a time per device).
+    in a fixed array inside the library (at most REDUCED_MAX_PARTIALS of them, one call at a time per device);
+    a float32 call additionally takes its scratch memory from `workspace` (a uint8 tensor of at least
+    `workspace_bytes(x, plan, co)` bytes) instead of allocating it.
     With `mask_y` (x's shape and dtype) x is contracted as x * m, m = 1 where mask_y > 0, else mask_alpha, and 0 where
     |mask_y| >= mask_clamp (mask_clamp < 0: unbounded): the backward of a fused activation applied to the incoming
     gradient while it is staged.  Ask `supports_mask` first."""
@@ -180,6 +195,12 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
         offset += nky * nkx * co * ci
+    if workspace is not None:
+        if workspace.dtype != torch.uint8 or workspace.device != x.device or not workspace.is_contiguous():
+            raise RuntimeError('workspace must be a dense uint8 tensor on the device of x')
+        p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel()
+    else:
+        workspace = _attach_workspace(p, _lib.lib().sg_conv2d_workspace_bytes, x)   # (kept alive until the launch is queued)
     partial = None
     if reduce_x is not None and out is not None:
         label = f'{_lib.lib().sg_conv2d_kernel(ctypes.byref(p)).decode()}<{_DTYPE_NAME[x.dtype]}>' if _lib.profiling() else ''
@@ -201,6 +222,17 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     if reduce_x is not None:
         return y, (partial.sum(dim=1) if partial.shape[1] > 1 else partial[:, 0])
     return y
+
+
+def workspace_bytes(x, plan, co):
+    """Bytes of scratch memory `conv2d(x, ..., plan, co)` uses (0 for 16-bit tensors)."""
+    n, ci, h, w = x.shape
+    p = Conv2dParams(dtype=_lib.dtype_code(x), n=n, ci=ci, h=h, w_in=w, co=co, num_phases=len(plan.phases))
+    offset = 0
+    for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
+        p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
+        offset += nky * nkx * co * ci
+    return int(_lib.lib().sg_conv2d_workspace_bytes(ctypes.byref(p)))
 
 
 def supports_mask(x, plan, co, out_hw=None, reduce=False):
@@ -230,7 +262,8 @@ class Conv2dWgradParams(ctypes.Structure):
                 ('cg', ctypes.c_int32), ('gh', ctypes.c_int32), ('gw', ctypes.c_int32),
                 ('step', ctypes.c_int32), ('dy0', ctypes.c_int32), ('dx0', ctypes.c_int32),
                 ('nky', ctypes.c_int32), ('nkx', ctypes.c_int32),
-                ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float)]
+                ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
 def _wgrad_params(x, g, kh, kw, stride, padding, x_scale=None, g_scale=None, dw=None, mask_y=None, mask_alpha=1.0, mask_clamp=-1.0):
@@ -272,6 +305,7 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, padding=0, x_scale=None, g_scale=None, 
         if mask_y is not None and (mask_y.shape != g.shape or mask_y.dtype != g.dtype or not mask_y.is_contiguous()):
             raise RuntimeError('mask_y must be dense and match g')
         p = _wgrad_params(x, g, kh, kw, stride, padding, x_scale, g_scale, dw, mask_y, mask_alpha, mask_clamp)
+        work = _attach_workspace(p, _lib.lib().sg_conv2d_wgrad_workspace_bytes, x)   # noqa: F841
         label = ''
         if _lib.profiling():
             name = _lib.lib().sg_conv2d_wgrad_kernel(ctypes.byref(p)).decode()

@@ -37,4 +37,28 @@ __device__ __forceinline__ void half_range_scale(const unsigned* slot, int tenso
     half_range_scale(amax, mul, inv);
 }
 
+// ---- split tensors ---------------------------------------------------------------------------------------------
+// The kernels that multiply float operands as pairs of halves read them from a copy made once per call in front
+// of them ("split rows"): for every chunk cb of 32 channels and every row r (a pixel of a sample of an activation
+// tensor, or a (tap, output channel) row of a weight tensor) 128 bytes [plane 0: 32 halves h0][plane 1: 32 halves
+// h1], chunk-major: activations at byte ((n * chunks + cb) * pixels + r) * 128, weights at (cb * rows + r) * 128,
+// chunks = ceil(c / 32), channels beyond c zero; v * mul = h0 + h1 (+ 2^-22 |v|), mul the tensor's half-range
+// scale.  A tile of such rows goes to LDS with plain 16-byte copies of contiguous runs.
+constexpr int kSplitChunk = 32;
+inline int64_t split_chunks(int c) { return (c + kSplitChunk - 1) / kSplitChunk; }
+inline size_t split_bytes(int64_t rows, int c) { return (size_t)rows * split_chunks(c) * 128; }
+
+// Scratch memory of the current device for work on `stream`: grow-only, one buffer per (device, stream), kept until
+// the process ends; contents are only valid between the calls of one entry point.  Growing allocates, so the
+// first call of a given size must not be inside a stream capture.  nullptr (and the error message set) on failure.
+void* split_workspace(hipStream_t stream, size_t bytes);
+
+// x[n][c][pixels] float (dense NCHW) -> split rows [n][chunks][pixels], each value times scale[n][c] (when given)
+// and the half-range scale of words (tensor_word, scale_word) of `slot`.
+int split_pixels(hipStream_t stream, const float* x, const float* scale, int n, int c, int64_t pixels, const unsigned* slot,
+                 int tensor_word, int scale_word, void* out);
+
+// w[rows][c] float -> split rows [chunks][rows], times the half-range scale of word `tensor_word` of `slot`.
+int split_rows(hipStream_t stream, const float* w, int64_t rows, int c, const unsigned* slot, int tensor_word, void* out);
+
 }  // namespace sg

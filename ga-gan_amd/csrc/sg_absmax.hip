@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "sg_common.h"
 
@@ -75,7 +78,144 @@ unsigned* ring_of_current_device() {
     return ptr;
 }
 
+// One float4 of scaled values -> the two half pieces of each, as two 8-byte packets.
+__device__ __forceinline__ void split4(const float (&v)[4], uint2& p0, uint2& p1) {
+    unsigned short h0[4], h1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const _Float16 a = (_Float16)v[j];
+        h0[j] = __builtin_bit_cast(unsigned short, a);
+        h1[j] = __builtin_bit_cast(unsigned short, (_Float16)(v[j] - (float)a));
+    }
+    p0 = make_uint2(h0[0] | ((unsigned)h0[1] << 16), h0[2] | ((unsigned)h0[3] << 16));
+    p1 = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+}
+
+// x[n][c][pixels] -> split rows.  A workgroup transposes 32 channels x 64 pixels through LDS: reads run along
+// pixels (256 bytes per channel), writes along channels (a pixel's chunk is 128 contiguous bytes).
+__global__ void __launch_bounds__(256) split_pixels_kernel(const float* __restrict__ x, const float* __restrict__ scale, int c,
+                                                           int64_t pixels, int chunks, const unsigned* slot, int tensor_word,
+                                                           int scale_word, unsigned char* __restrict__ out) {
+    __shared__ float s[32][65];
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int cb = blockIdx.y, n = blockIdx.z;
+    float mul, inv;
+    half_range_scale(slot, tensor_word, scale_word, scale != nullptr, mul, inv);
+    const float* xn = x + (int64_t)n * c * pixels;
+    const bool vec = (pixels % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    for (int it = threadIdx.x; it < 32 * 16; it += 256) {
+        const int ch = it >> 4, q = it & 15;
+        const int cc = cb * 32 + ch;
+        const int64_t p = p0 + q * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cc < c) {
+            const float f = mul * (scale ? scale[(int64_t)n * c + cc] : 1.f);
+            const float* src = xn + (int64_t)cc * pixels + p;
+            if (vec && p + 3 < pixels) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                v[0] = t.x * f; v[1] = t.y * f; v[2] = t.z * f; v[3] = t.w * f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (p + j < pixels) v[j] = src[j] * f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[ch][q * 4 + j] = v[j];
+    }
+    __syncthreads();
+    const int px = threadIdx.x >> 2, q = threadIdx.x & 3;   // pixel of the tile, 8 channels of the chunk
+    if (p0 + px >= pixels) return;
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { a[j] = s[q * 8 + j][px]; b[j] = s[q * 8 + 4 + j][px]; }
+    uint2 a0, a1, b0, b1;
+    split4(a, a0, a1);
+    split4(b, b0, b1);
+    unsigned char* dst = out + (((int64_t)n * chunks + cb) * pixels + p0 + px) * 128 + q * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+    *reinterpret_cast<uint4*>(dst + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+}
+
+// w[rows][c] -> split rows: a lane makes 8 channels of one row.
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ w, int64_t rows, int c, int chunks,
+                                                         const unsigned* slot, int tensor_word, unsigned char* __restrict__ out) {
+    float mul, inv;
+    half_range_scale(slot, tensor_word, 0, false, mul, inv);
+    const int64_t items = rows * chunks * 4;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(it & 3);
+        const int64_t rc = it >> 2;
+        const int cb = (int)(rc % chunks);
+        const int64_t r = rc / chunks;
+        const float* src = w + r * c + cb * 32 + q * 8;
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            a[j] = (cb * 32 + q * 8 + j < c) ? src[j] * mul : 0.f;
+            b[j] = (cb * 32 + q * 8 + 4 + j < c) ? src[4 + j] * mul : 0.f;
+        }
+        uint2 a0, a1, b0, b1;
+        split4(a, a0, a1);
+        split4(b, b0, b1);
+        unsigned char* dst = out + ((int64_t)cb * rows + r) * 128 + q * 16;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        *reinterpret_cast<uint4*>(dst + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+    }
+}
+
 }  // namespace
+
+void* split_workspace(hipStream_t stream, size_t bytes) {
+    struct Buffer { void* ptr = nullptr; size_t bytes = 0; };
+    static std::mutex mutex;
+    static std::map<std::pair<int, hipStream_t>, Buffer> buffers;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        fail((int)hipErrorInvalidDevice, "split workspace: no usable current device");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(mutex);
+    Buffer& b = buffers[{dev, stream}];
+    if (b.bytes < bytes) {
+        // (work queued on the old buffer has its own reference to nothing: wait for the stream before freeing)
+        if (b.ptr) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(b.ptr);
+            b = Buffer{};
+        }
+        const size_t want = bytes + bytes / 4;
+        void* ptr = nullptr;
+        const hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) {
+            fail((int)e, "split workspace: cannot allocate %zu bytes: %s", want, hipGetErrorString(e));
+            return nullptr;
+        }
+        b.ptr = ptr;
+        b.bytes = want;
+    }
+    return b.ptr;
+}
+
+int split_pixels(hipStream_t stream, const float* x, const float* scale, int n, int c, int64_t pixels, const unsigned* slot,
+                 int tensor_word, int scale_word, void* out) {
+    if (n == 0 || pixels == 0) return SG_OK;
+    const int chunks = (int)split_chunks(c);
+    const int64_t tiles = (pixels + 63) / 64;
+    SG_REQUIRE(tiles <= INT32_MAX && chunks <= 65535 && n <= 65535, SG_ERR_INVALID_ARGUMENT, "split: tensor is too large");
+    hipLaunchKernelGGL(split_pixels_kernel, dim3((unsigned)tiles, (unsigned)chunks, (unsigned)n), dim3(256), 0, stream, x, scale, c,
+                       pixels, chunks, slot, tensor_word, scale_word, (unsigned char*)out);
+    return check_launch("split_pixels");
+}
+
+int split_rows(hipStream_t stream, const float* w, int64_t rows, int c, const unsigned* slot, int tensor_word, void* out) {
+    if (rows == 0) return SG_OK;
+    const int chunks = (int)split_chunks(c);
+    const int64_t items = rows * chunks * 4;
+    const unsigned blocks = (unsigned)std::min<int64_t>((items + 255) / 256, 4096);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, stream, w, rows, c, chunks, slot, tensor_word, (unsigned char*)out);
+    return check_launch("split_rows");
+}
 
 int absmax_measure(hipStream_t stream, const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc,
                    const float* d, int64_t nd, const unsigned** slot) {

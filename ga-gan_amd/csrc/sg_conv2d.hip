@@ -72,24 +72,6 @@ template <> struct Mma<__half> {
 // more than 2^17 below the tensor's maximum keeps an absolute error of 2^-40 of that maximum instead); the
 // products h0 h0', h0 h1' and h1 h0' are accumulated in float by the matrix instructions, and what is dropped,
 // h1 h1', is below 2^-22 of the product as well.  A non-finite input poisons the outputs it reaches.
-__device__ __forceinline__ unsigned pack_halves(_Float16 lo, _Float16 hi) {
-    return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-}
-
-// Two floats a, b -> two dwords p0, p1 of half pairs (a's piece in the low half).
-__device__ __forceinline__ void split2_pair(float a, float b, unsigned& p0, unsigned& p1) {
-    const _Float16 a0 = (_Float16)a, b0 = (_Float16)b;
-    p0 = pack_halves(a0, b0);
-    p1 = pack_halves((_Float16)(a - (float)a0), (_Float16)(b - (float)b0));
-}
-
-// One float -> its two half bit patterns (the scalar staging path).
-__device__ __forceinline__ void split2(float v, unsigned& h0, unsigned& h1) {
-    const _Float16 v0 = (_Float16)v;
-    h0 = __builtin_bit_cast(unsigned short, v0);
-    h1 = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)v0));
-}
-
 // The three partial products of the split float path, smallest first.
 __device__ __forceinline__ void mma_split(const uint4 (&a)[2], const uint4 (&b)[2], f32x4_t& c) {
     using M = Mma<__half>;
@@ -98,116 +80,21 @@ __device__ __forceinline__ void mma_split(const uint4 (&a)[2], const uint4 (&b)[
     M::run(a[0], b[0], c);
 }
 
-// Split-float form of stage_pixels / stage_pixels_vec: the footprint of 32 channels from c0 on, as two half
-// planes per pixel row (plane p at byte p * 64, channel c at 2 c), every value times the power of two `mul`.  An item is one channel pair x VEC
-// consecutive pixels of a row (VEC = 4: one aligned 16-byte packet per channel; VEC = 1: any row length).  The
-// copy is cut into a load half (global memory -> registers, with the two channel scales) and a store half
-// (scale, split, LDS) so that a caller can keep the loads of the next chunk in flight behind its multiplies.
-struct SplitGeom {
-    const float* x;
-    const float* scale;
-    int n_total, c_total, h, w, img0, imgs, iy0, ix0, lh, lw;
-    int vx0, nv, items;
-    float mul;
-};
-
-template <int VEC>
-__device__ __forceinline__ SplitGeom split_geom(const float* x, const float* scale, int n_total, int c_total, int h, int w,
-                                                int img0, int imgs, int iy0, int ix0, int lh, int lw, float mul) {
-    SplitGeom g{x, scale, n_total, c_total, h, w, img0, imgs, iy0, ix0, lh, lw, 0, 0, 0, mul};
-    g.vx0 = floor_div_i(ix0, VEC);
-    g.nv = floor_div_i(ix0 + lw - 1, VEC) - g.vx0 + 1;
-    g.items = imgs * lh * g.nv * 16;
-    return g;
-}
-
-template <int VEC> struct SplitItem {
-    float va[VEC], vb[VEC];   // channel c and c + 1
-    float s0, s1;
-};
-
-template <int VEC>
-__device__ __forceinline__ void split_item_load(const SplitGeom& g, int c0, int it, SplitItem<VEC>& d) {
-#pragma unroll
-    for (int j = 0; j < VEC; j++) d.va[j] = d.vb[j] = 0.f;
-    d.s0 = d.s1 = g.mul;
-    if (it >= g.items) return;
-    const int cg = it & 15;
-    int r = it >> 4;
-    const int v = r % g.nv; r /= g.nv;
-    const int ry = r % g.lh;
-    const int ri = r / g.lh;
-    const int iy = g.iy0 + ry, n = g.img0 + ri, px0 = (g.vx0 + v) * VEC;
-    const int c = c0 + cg * 2;
-    if (!(iy >= 0 && iy < g.h && n < g.n_total && c < g.c_total && px0 >= 0 && px0 < g.w)) return;
-    const int64_t plane = (int64_t)g.h * g.w;
-    const float* src = g.x + ((int64_t)n * g.c_total + c) * plane + (int64_t)iy * g.w + px0;
-    const bool two = c + 1 < g.c_total;
-    if constexpr (VEC == 4) {
-        const float4 fa = *reinterpret_cast<const float4*>(src);
-        d.va[0] = fa.x; d.va[1] = fa.y; d.va[2] = fa.z; d.va[3] = fa.w;
-        if (two) {
-            const float4 fb = *reinterpret_cast<const float4*>(src + plane);
-            d.vb[0] = fb.x; d.vb[1] = fb.y; d.vb[2] = fb.z; d.vb[3] = fb.w;
-        }
-    } else {
-        d.va[0] = src[0];
-        if (two) d.vb[0] = src[plane];
-    }
-    if (g.scale) {
-        d.s0 = g.scale[(int64_t)n * g.c_total + c] * g.mul;
-        d.s1 = two ? g.scale[(int64_t)n * g.c_total + c + 1] * g.mul : 0.f;
-    }
-}
-
-template <int VEC>
-__device__ __forceinline__ void split_item_store(unsigned char* s_dst, const SplitGeom& g, int it, const SplitItem<VEC>& d) {
-    if (it >= g.items) return;
-    const int cg = it & 15;
-    int r = it >> 4;
-    const int v = r % g.nv; r /= g.nv;   // r = ri * lh + ry
-    unsigned char* row = s_dst + (r * g.lw) * kPitchSplit + cg * 4;
-    const int rx0 = (g.vx0 + v) * VEC - g.ix0;
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-        const int rx = rx0 + j;
-        if (rx < 0 || rx >= g.lw) continue;
-        unsigned p0, p1;
-        split2_pair(d.va[j] * d.s0, d.vb[j] * d.s1, p0, p1);
-        unsigned char* dst = row + rx * kPitchSplit;
-        *reinterpret_cast<unsigned*>(dst) = p0;
-        *reinterpret_cast<unsigned*>(dst + 64) = p1;
-    }
-}
-
-template <int VEC, int THREADS>
-__device__ __forceinline__ void stage_pixels_split(unsigned char* s_dst, const SplitGeom& g, int c0, int first_item) {
-    constexpr int U = 4;   // loads in flight per lane
-    for (int base = first_item + threadIdx.x; base < g.items; base += U * THREADS) {
-        SplitItem<VEC> d[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) split_item_load<VEC>(g, c0, base + u * THREADS, d[u]);
-#pragma unroll
-        for (int u = 0; u < U; u++) split_item_store<VEC>(s_dst, g, base + u * THREADS, d[u]);
-    }
-}
-
-// Four consecutive channels of one weight row (times `mul`) -> the two half planes of the LDS row (8 bytes each).
-__device__ __forceinline__ void split_weight_store(unsigned char* dst, const float4& v, float mul) {
-    unsigned lo[2], hi[2];
-    split2_pair(v.x * mul, v.y * mul, lo[0], lo[1]);
-    split2_pair(v.z * mul, v.w * mul, hi[0], hi[1]);
-#pragma unroll
-    for (int pl = 0; pl < 2; pl++) *reinterpret_cast<uint2*>(dst + pl * 64) = make_uint2(lo[pl], hi[pl]);
-}
-
 struct Tile {
     int split_k;          // > 1: input-channel chunks are divided over blockIdx.z, partial sums added atomically
     int tw, th, imgs;     // pixel tile in phase coordinates; tw * th * imgs <= 256 (slots beyond it are idle)
     int lw, lh;           // LDS footprint of one image's tile (pixels)
     int tiles_a, tiles_b, tiles_img;
     int vec_epi;          // epilogue through LDS with 16-byte global accesses (8 pixels of one channel per lane)
-    const unsigned* amax; // float path: largest magnitudes of x, w and in_scale (bit patterns), see sg_absmax.h
+    // float path (sg_absmax.h): largest magnitudes of x, w and in_scale (bit patterns); x and the packed weights as
+    // split rows; chunks of 32 input channels
+    const unsigned* amax;
+    const unsigned char* xs;
+    const unsigned char* ws;
+    int chunks;
+    int64_t w_rows;       // rows of the whole packed weight tensor
+    int max_taps;         // most taps of any phase
+    int x_double;         // LDS holds two input footprints (the next chunk's is written while this one is read)
 };
 
 // Pixel slot (0..255) of a workgroup -> column, row and image within its tile; ri >= t.imgs marks an idle slot.
@@ -421,15 +308,16 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
 
     const bool w_vec = (p.ci % (16 / (int)sizeof(T)) == 0);
 
-    // float path: the powers of two that bring both operands into the range of a half, and their inverses
-    float mul_x = 1.f, inv_x = 1.f, mul_w = 1.f, inv_w = 1.f;
+    // float path: the inverses of the powers of two that brought both operands into the range of a half
+    float inv_x = 1.f, inv_w = 1.f;
     if constexpr (SPLIT) {
-        half_range_scale(t.amax, 0, 2, p.in_scale != nullptr, mul_x, inv_x);
-        half_range_scale(t.amax, 1, 3, false, mul_w, inv_w);
+        float mul;
+        half_range_scale(t.amax, 0, 2, p.in_scale != nullptr, mul, inv_x);
+        half_range_scale(t.amax, 1, 3, false, mul, inv_w);
     }
 
     // ---- split float path: multiply the staged taps [g0, g0 + gtaps) of the weight chunk ------------------------
-    auto split_multiply = [&](int g0, int gtaps) {
+    auto split_multiply = [&](const unsigned char* s_w, const unsigned char* s_in, int g0, int gtaps) {
         for (int tl = 0; tl < gtaps; tl++) {
             const int tap = g0 + tl;
             const int ky = tap / ph.nkx, kx = tap - ky * ph.nkx;
@@ -453,103 +341,145 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         }
     };
 
-    bool contracted = false;   // the fast split path below has already run the whole channel loop
     if constexpr (SPLIT) {
-        // Fast form (rows of whole aligned packets, channel count a multiple of 4): a pipeline over (chunk, tap
-        // group) stages in which the global loads of the next stage - kSplitTaps taps of weights, and the input
-        // footprint when a new chunk begins - are issued into registers before the multiplies of the current
-        // one, and split / written to LDS after them.
-        const bool fast = w_vec && (p.w_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
-        if (fast) {
-            constexpr int W_IT = (kSplitTaps * BM * 8 + THREADS - 1) / THREADS;   // packets of 4 channels per lane
-            constexpr int X_IT = 2048 / THREADS;                                                 // input items per lane held in registers
-            const SplitGeom g = split_geom<4>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw, mul_x);
-            const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
-            const int c_begin = ksplit * chunks_per_split * KCH;
-            const int c_end = min(p.ci, c_begin + chunks_per_split * KCH);
-            float4 wreg[W_IT];
-            SplitItem<4> xreg[X_IT];
-            auto w_load = [&](int c0, int g0) {
-                const int gtaps = min(kSplitTaps, taps - g0);
+        // Float path: both operands come as split rows (sg_absmax.h) - per pixel (or weight row) and chunk of 32
+        // channels 128 contiguous bytes, the LDS row without its padding - so staging is 16-byte copies.  A pipeline
+        // over (chunk, tap group) stages: the global loads of the next stage - kSplitTaps taps of weights, and the
+        // input footprint when a new chunk begins - are issued into registers before the multiplies of the current
+        // one and written to LDS after them.
+        constexpr int W_IT = (kSplitTaps * BM * 8 + THREADS - 1) / THREADS;   // 16-byte pieces per lane
+        constexpr int X_IT = 8;                                               // input pieces per lane held in registers
+        const unsigned char* __restrict__ xs = t.xs;
+        const unsigned char* __restrict__ ws = t.ws + (ph.w_offset / p.ci) * (int64_t)128;   // (this phase's first row)
+        const int x_items = t.imgs * lh * lw * 8;
+        const int64_t x_plane8 = (int64_t)p.h * p.w_in * 8;   // 16-byte units from one chunk of a sample to the next
+        const int chunks = t.chunks, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
+        const int cb_begin = ksplit * chunks_per_split, cb_end = min(chunks, cb_begin + chunks_per_split);
+        uint4 wreg_a[W_IT], wreg_b[W_IT], xreg[X_IT];
+        auto w_load = [&](uint4 (&wreg)[W_IT], int cb, int g0) {
+            const int gtaps = min(kSplitTaps, taps - g0);
 #pragma unroll
-                for (int k = 0; k < W_IT; k++) {
-                    const int e = tid + k * THREADS;
-                    const int q = e & 7, row = e >> 3;
-                    const int o = row % BM, tap = g0 + row / BM;
-                    const int c = c0 + q * 4;
-                    wreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < gtaps * BM * 8 && m0 + o < p.co && c < p.ci)
-                        wreg[k] = *reinterpret_cast<const float4*>(w + ((int64_t)tap * p.co + m0 + o) * p.ci + c);
-                }
-            };
-            auto w_commit = [&](int g0) {
-                const int gtaps = min(kSplitTaps, taps - g0);
-#pragma unroll
-                for (int k = 0; k < W_IT; k++) {
-                    const int e = tid + k * THREADS;
-                    if (e < gtaps * BM * 8) split_weight_store(s_w + (e >> 3) * PITCH + (e & 7) * 8, wreg[k], mul_w);
-                }
-            };
-            auto x_load = [&](int c0) {
-#pragma unroll
-                for (int k = 0; k < X_IT; k++) split_item_load<4>(g, c0, tid + k * THREADS, xreg[k]);
-            };
-            auto x_commit = [&](int c0) {
-#pragma unroll
-                for (int k = 0; k < X_IT; k++) split_item_store<4>(s_in, g, tid + k * THREADS, xreg[k]);
-                stage_pixels_split<4, THREADS>(s_in, g, c0, X_IT * THREADS);   // (footprints beyond the register window)
-            };
-            int c0 = c_begin, g0 = 0;
-            bool new_chunk = true;
-            if (c0 < c_end) {
-                w_load(c0, g0);
-                x_load(c0);
+            for (int k = 0; k < W_IT; k++) {
+                const int e = tid + k * THREADS;
+                const int piece = e & 7, row = e >> 3;
+                const int o = row % BM, tap = g0 + row / BM;
+                wreg[k] = make_uint4(0, 0, 0, 0);
+                if (cb < cb_end && e < gtaps * BM * 8 && m0 + o < p.co)
+                    wreg[k] = *reinterpret_cast<const uint4*>(ws + ((int64_t)cb * t.w_rows + (int64_t)tap * p.co + m0 + o) * 128 + piece * 16);
             }
-            while (c0 < c_end) {
-                __syncthreads();   // the previous stage's fragments have been read
-                if (new_chunk) x_commit(c0);
-                w_commit(g0);
-                __syncthreads();
-                int nc0 = c0, ng0 = g0 + kSplitTaps;
-                bool next_new = false;
-                if (ng0 >= taps) { ng0 = 0; nc0 = c0 + KCH; next_new = true; }
-                if (nc0 < c_end) {
-                    w_load(nc0, ng0);
-                    if (next_new) x_load(nc0);
-                }
-                split_multiply(g0, min(kSplitTaps, taps - g0));
-                c0 = nc0; g0 = ng0; new_chunk = next_new;
+        };
+        auto w_commit = [&](const uint4 (&wreg)[W_IT], unsigned char* s_w, int g0) {
+            const int gtaps = min(kSplitTaps, taps - g0);
+#pragma unroll
+            for (int k = 0; k < W_IT; k++) {
+                const int e = tid + k * THREADS;
+                if (e < gtaps * BM * 8) *reinterpret_cast<uint4*>(s_w + (e >> 3) * PITCH + (e & 7) * 16) = wreg[k];
             }
+        };
+        // Where piece e of the footprint lies in the split tensor, in 16-byte units for chunk 0 (-1: outside the
+        // tensor, zero).  The same for every chunk, so the divisions are done once per lane.
+        auto x_where = [&](int e) -> int64_t {
+            const int piece = e & 7;
+            int pix = e >> 3;
+            const int rx = pix % lw; pix /= lw;
+            const int ry = pix % lh;
+            const int ri = pix / lh;
+            const int iy = iy0 + ry, ix = ix0 + rx, n = img0 + ri;
+            if (e >= x_items || iy < 0 || iy >= p.h || ix < 0 || ix >= p.w_in || n >= p.n) return -1;
+            return (((int64_t)n * chunks * p.h + iy) * p.w_in + ix) * 8 + piece;
+        };
+        int64_t xoff[X_IT];
+#pragma unroll
+        for (int k = 0; k < X_IT; k++) xoff[k] = x_where(tid + k * THREADS);
+        auto x_fetch = [&](int cb, int64_t where) -> uint4 {   // (no branch: a piece outside is read at the tensor's start and dropped)
+            const uint4 v = *reinterpret_cast<const uint4*>(xs + (where < 0 ? 0 : (where + (int64_t)cb * x_plane8) * 16));
+            return where < 0 ? make_uint4(0, 0, 0, 0) : v;
+        };
+        auto x_load = [&](int cb) {
+#pragma unroll
+            for (int k = 0; k < X_IT; k++) xreg[k] = x_fetch(cb, xoff[k]);
+        };
+        auto x_commit = [&](unsigned char* s_in, int cb) {
+#pragma unroll
+            for (int k = 0; k < X_IT; k++) {
+                const int e = tid + k * THREADS;
+                if (e < x_items) *reinterpret_cast<uint4*>(s_in + (e >> 3) * PITCH + (e & 7) * 16) = xreg[k];
+            }
+            for (int e0 = X_IT * THREADS + tid; e0 < x_items; e0 += 4 * THREADS) {   // (footprints beyond the register window)
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = x_fetch(cb, x_where(e0 + u * THREADS));
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * THREADS;
+                    if (e < x_items) *reinterpret_cast<uint4*>(s_in + (e >> 3) * PITCH + (e & 7) * 16) = v[u];
+                }
+            }
+        };
+        // Stage = (chunk, tap group).  The weights of a stage are requested two stages ahead (two register sets
+        // used in turn) and written to the LDS buffer the current stage does not read, after its multiplies; the
+        // footprint of the next chunk is requested at the first stage of the current one and written - to a second
+        // footprint buffer when LDS has room for it (t.x_double), else after one more barrier - at its last stage.
+        // One barrier per stage: a wave's LDS writes and address arithmetic overlap the other waves' multiplies.
+        auto advance = [&](int& cb, int& g0) {
+            g0 += kSplitTaps;
+            if (g0 >= taps) { g0 = 0; cb++; }
+        };
+        const size_t x_bytes = (size_t)t.imgs * t.lh * t.lw * PITCH, w_bytes = (size_t)min(t.max_taps, kSplitTaps) * BM * PITCH;
+        unsigned char* s_x[2] = {smem, smem + (t.x_double ? x_bytes : 0)};
+        unsigned char* s_wb[2] = {smem + (t.x_double ? 2 : 1) * x_bytes, smem + (t.x_double ? 2 : 1) * x_bytes + w_bytes};
+        int cb = cb_begin, g0 = 0;          // the stage being multiplied
+        int cb1 = cb, g1 = g0;              // one and two stages ahead
+        advance(cb1, g1);
+        int cb2 = cb1, g2 = g1;
+        advance(cb2, g2);
+        int sidx = 0;                       // stage counter: picks the weight buffer
+        if (cb < cb_end) {
+            w_load(wreg_a, cb, g0);
+            x_load(cb);
+            w_load(wreg_b, cb1, g1);
+#ifndef BAND_ABL_NOSTAGE
+            x_commit(s_x[cb & 1], cb);
+            w_commit(wreg_a, s_wb[0], g0);
+#endif
+            __syncthreads();
         }
-        contracted = fast;
+        // On entry the LDS buffer sidx & 1 holds this stage's weights, `next` holds (or awaits) those of the stage
+        // after it and `far` is free: it receives the request for two stages on.
+        auto stage = [&](uint4 (&next)[W_IT], uint4 (&far)[W_IT]) {
+            const bool first = g0 == 0, last = cb1 != cb;
+            w_load(far, cb2, g2);
+            if (first && cb + 1 < cb_end) x_load(cb + 1);
+#ifndef BAND_ABL_NOCOMPUTE
+            split_multiply(s_wb[sidx & 1], s_x[cb & 1], g0, min(kSplitTaps, taps - g0));
+#endif
+#ifndef BAND_ABL_NOSTAGE
+            if (cb1 < cb_end) {
+                w_commit(next, s_wb[(sidx + 1) & 1], g1);
+                if (last) {
+                    if (!t.x_double) __syncthreads();   // every wave has read the footprint of this chunk
+                    x_commit(s_x[cb1 & 1], cb1);
+                }
+            }
+#endif
+            __syncthreads();
+            cb = cb1; g0 = g1;
+            cb1 = cb2; g1 = g2;
+            advance(cb2, g2);
+            sidx++;
+        };
+        while (cb < cb_end) {
+            stage(wreg_b, wreg_a);
+            if (cb >= cb_end) break;
+            stage(wreg_a, wreg_b);
+        }
     }
     const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
     const int c_begin = ksplit * chunks_per_split * KCH;
-    const int c_end = contracted ? c_begin : min(p.ci, c_begin + chunks_per_split * KCH);
+    const int c_end = SPLIT ? c_begin : min(p.ci, c_begin + chunks_per_split * KCH);
     for (int c0 = c_begin; c0 < c_end; c0 += KCH) {
         __syncthreads();   // everyone is done reading the previous chunk
-        if constexpr (SPLIT) {
-            // (slow form of the split path: rows that are no whole packets, or channel counts that are no multiple of 4)
-            const SplitGeom g = split_geom<1>(x, p.in_scale, p.n, p.ci, p.h, p.w_in, img0, t.imgs, iy0, ix0, lh, lw, mul_x);
-            stage_pixels_split<1, THREADS>(s_in, g, c0, 0);
-            for (int g0 = 0; g0 < taps; g0 += kSplitTaps) {
-                const int gtaps = min(kSplitTaps, taps - g0);
-                if (g0 > 0) __syncthreads();   // the previous group's fragments have been read
-                for (int e = tid; e < gtaps * BM * KCH; e += THREADS) {
-                    const int cc = e % KCH, row = e / KCH;
-                    const int o = row % BM, tap = g0 + row / BM;
-                    float v = 0.f;
-                    if (m0 + o < p.co && c0 + cc < p.ci) v = w[((int64_t)tap * p.co + m0 + o) * p.ci + c0 + cc];
-                    unsigned h0, h1;
-                    split2(v * mul_w, h0, h1);
-                    unsigned short* dst = reinterpret_cast<unsigned short*>(s_w + row * PITCH + cc * 2);
-                    dst[0] = (unsigned short)h0; dst[32] = (unsigned short)h1;
-                }
-                __syncthreads();
-                split_multiply(g0, gtaps);
-            }
-        } else {
+        if constexpr (!SPLIT) {
         stage_tile<T>(s_in, x, p.in_scale, p.n, p.ci, p.h, p.w_in, c0, img0, t.imgs, iy0, ix0, lh, lw);
         // ---- stage the weight chunk: [tap][BM][channel] ----------------------------------------
         if (w_vec) {
@@ -822,7 +752,7 @@ Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     if (split) {
         // Rows of 144 bytes: pick the rows x images per tile that fill the most pixel slots within the LDS budget
         // (slots beyond imgs * th * tw idle).  Tiles that feed the per-image reduction keep whole 16-pixel groups.
-        const size_t budget = 152 * 1024 / pitch - (size_t)min(max_taps, kSplitTaps) * 64;
+        const size_t budget = 152 * 1024 / pitch - 2 * (size_t)min(max_taps, kSplitTaps) * 64;   // (two weight buffers)
         int best_th = 1, best_imgs = 1, best_used = 0;
         for (int th = t.th; th >= 1; th = (th > 1) ? (th + 1) / 2 : 0) {
             if (!exact && (t.tw * th) % 16 != 0) break;
@@ -872,7 +802,14 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     const int64_t tiles_px = tiles * p.num_phases;
     const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) * max_split >= 256) ? 4 : 1;
     const int BM = 16 * m_tiles;
-    size_t lds = ((size_t)t.imgs * t.lh * t.lw + (size_t)(SPLIT ? std::min(max_taps, kSplitTaps) : max_taps) * BM) * PITCH;
+    size_t lds = ((size_t)t.imgs * t.lh * t.lw + (size_t)max_taps * BM) * PITCH;
+    t.max_taps = max_taps;
+    t.x_double = 0;
+    if constexpr (SPLIT) {   // two weight buffers of kSplitTaps taps, and two input footprints where they fit
+        const size_t x_rows = (size_t)t.imgs * t.lh * t.lw, w_rows = (size_t)std::min(max_taps, kSplitTaps) * BM;
+        t.x_double = (2 * x_rows + 2 * w_rows) * PITCH <= 160 * 1024;
+        lds = ((t.x_double ? 2 : 1) * x_rows + 2 * w_rows) * PITCH;
+    }
     SG_REQUIRE(lds <= 160 * 1024, SG_ERR_UNSUPPORTED, "conv2d: tile needs %zu bytes of LDS", lds);
     t.split_k = 1;
     {
@@ -893,6 +830,9 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
                 (!p.reduce_out || aligned16(p.reduce_x));
     if (t.vec_epi) lds = std::max(lds, (size_t)kPixels * (BM + 4) * sizeof(float));
     t.amax = nullptr;
+    t.xs = t.ws = nullptr;
+    t.chunks = 0;
+    t.w_rows = 0;
     if constexpr (SPLIT) {
         int64_t w_elems = 0;
         for (int i = 0; i < p.num_phases; i++)
@@ -900,6 +840,22 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
         if (int rc = absmax_measure(stream, (const float*)p.x, (int64_t)p.n * p.ci * p.h * p.w_in, (const float*)p.w, w_elems,
                                     p.in_scale, (int64_t)p.n * p.ci, nullptr, 0, &t.amax))
             return rc;
+        const int64_t pixels = (int64_t)p.h * p.w_in, w_rows = w_elems / p.ci;
+        const size_t x_bytes = split_bytes((int64_t)p.n * pixels, p.ci), need = x_bytes + split_bytes(w_rows, p.ci);
+        unsigned char* work = (unsigned char*)p.workspace;
+        if (work != nullptr) {
+            SG_REQUIRE(p.workspace_bytes >= need && (reinterpret_cast<uintptr_t>(work) & 255u) == 0, SG_ERR_INVALID_ARGUMENT,
+                       "conv2d: workspace of %zu bytes (need %zu, 256-byte aligned)", p.workspace_bytes, need);
+        } else {
+            work = (unsigned char*)split_workspace(stream, need);
+            if (work == nullptr) return (int)hipErrorOutOfMemory;
+        }
+        if (int rc = split_pixels(stream, (const float*)p.x, p.in_scale, p.n, p.ci, pixels, t.amax, 0, 2, work)) return rc;
+        if (int rc = split_rows(stream, (const float*)p.w, w_rows, p.ci, t.amax, 1, work + x_bytes)) return rc;
+        t.xs = work;
+        t.ws = work + x_bytes;
+        t.chunks = (int)split_chunks(p.ci);
+        t.w_rows = w_rows;
     }
     dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)(p.num_phases * t.split_k));
     auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
@@ -1136,6 +1092,19 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
     return fail(SG_ERR_UNSUPPORTED, "conv2d_wgrad: dtype %d is not supported (f32, f16, bf16)", p->dtype);
 }
 
+extern "C" size_t sg_conv2d_workspace_bytes(const sg_conv2d_params* p) {
+    if (p == nullptr || p->dtype != SG_F32 || p->n <= 0 || p->ci <= 0 || p->co <= 0 || p->num_phases < 1 || p->num_phases > 4) return 0;
+    int64_t w_elems = 0;
+    for (int i = 0; i < p->num_phases; i++)
+        w_elems = std::max<int64_t>(w_elems, p->phase[i].w_offset + (int64_t)p->phase[i].nky * p->phase[i].nkx * p->co * p->ci);
+    return sg::split_bytes((int64_t)p->n * p->h * p->w_in, p->ci) + sg::split_bytes(w_elems / p->ci, p->ci);
+}
+
+extern "C" size_t sg_conv2d_wgrad_workspace_bytes(const sg_conv2d_wgrad_params* p) {
+    if (p == nullptr || !sg::wgrad_f32_eligible(*p) || p->n <= 0) return 0;
+    return sg::split_bytes((int64_t)p->n * p->h * p->w_in, p->cx) + sg::split_bytes((int64_t)p->n * p->gh * p->gw, p->cg);
+}
+
 extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
     if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return -1;
     if (sg::conv1x1_few_eligible(*p)) return sg::conv1x1_few_reduce_rows(*p);
@@ -1230,6 +1199,9 @@ extern "C" int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, s
                "conv2d_reduced: reduce_x and reduce_sum must not be NULL");
     SG_REQUIRE(p->reduce_out == nullptr, SG_ERR_INVALID_ARGUMENT,
                "conv2d_reduced: reduce_out must be NULL (the partial rows live in the library's own array)");
+    SG_REQUIRE(p->workspace != nullptr || sg_conv2d_workspace_bytes(p) == 0, SG_ERR_INVALID_ARGUMENT,
+               "conv2d_reduced: a float32 call needs p->workspace (%zu bytes): this entry point allocates nothing",
+               sg_conv2d_workspace_bytes(p));
     SG_REQUIRE(p->n >= 0 && p->co >= 1, SG_ERR_INVALID_ARGUMENT, "conv2d: bad tensor sizes");
     if (p->n == 0) return SG_OK;
     const int rows = sg_conv2d_reduce_rows(p);

@@ -37,81 +37,79 @@ constexpr int BC = 64;             // channels of either operand per workgroup
 constexpr int kRowBytes = 288;     // bytes per LDS pixel row
 constexpr int kMaxPixelRows = 560; // x footprint + g tile, in pixel rows: 157.5 KB
 
+#ifdef BAND_ABL_STAMPS
+__device__ unsigned long long wgrad_stamps[4][16];   // [wave][phase sums: stage, barrier, compute, tiles, epilogue]
+#define WSTAMP() __builtin_amdgcn_s_memtime()
+#endif
+
 struct WTile {
     int tw, th, imgs;             // gradient pixels per tile: tw (8, 16 or 32) x th (a multiple of 32 / tw) x imgs
     int lw, lh;                   // x footprint of one image's tile
     int tiles_a, tiles_b, tiles_img;
 };
 
-__device__ __forceinline__ int floor_div4(int a) { return (a >= 0) ? a / 4 : -((-a + 3) / 4); }
+// Copy rows [iy0, iy0 + lh) x columns [ix0, ix0 + lw) of chunks cb0 and cb0 + 1 (64 channels) and images img0 ..
+// img0 + imgs - 1 of a tensor given as split rows (sg_absmax.h: per chunk of 32 channels and pixel 128 bytes,
+// [plane 0][plane 1]) into LDS as [image][row][column] rows of kRowBytes; zero outside the tensor.  16-byte pieces,
+// U per lane; `load` only issues the requests (so that the caller can put both operands' in flight before it waits
+// for either), `store` writes them to LDS and copies what lies beyond the register window (rare geometries).
+template <int U> struct Stager {
+    uint4 val[U];
+    bool keep[U];
+    const unsigned char* xs;
+    int64_t lane_off;
+    int chunks, n_total, h, w, img0, iy0, ix0, lh, lw, items, piece;
+    bool chunk_ok;
 
-// One float (already scaled into a half's range) -> its two half pieces, at `dst` and 128 bytes further.
-__device__ __forceinline__ void store_split(unsigned char* dst, float v) {
-    const _Float16 h0 = (_Float16)v;
-    *reinterpret_cast<_Float16*>(dst) = h0;
-    *reinterpret_cast<_Float16*>(dst + 128) = (_Float16)(v - (float)h0);
-}
-
-// Copy rows [iy0, iy0 + lh) x columns [ix0, ix0 + lw) of channels c0 .. c0 + 63 and images img0 .. img0 + imgs - 1
-// of a dense NCHW float tensor into LDS as [image][row][column][plane][channel] halves, times scale[n, c] (when
-// given) and the power of two `mul`; zero outside the tensor.  A lane owns one channel and moves aligned 16-byte
-// packets (VEC) or single floats.
-template <bool VEC>
-__device__ __forceinline__ void stage(unsigned char* s_dst, const float* __restrict__ x, const float* __restrict__ scale, float mul,
-                                      int n_total, int c_total, int h, int w, int c0, int img0, int imgs, int iy0, int ix0, int lh,
-                                      int lw) {
-    const int64_t plane = (int64_t)h * w;
-    const int ch = threadIdx.x & 63, c = c0 + ch;
-    if constexpr (VEC) {
-        const int vx0 = floor_div4(ix0);
-        const int nv = floor_div4(ix0 + lw - 1) - vx0 + 1;
-        const int items = imgs * lh * nv;
-        constexpr int U = 12;   // packets in flight per lane: the loop is bound by memory latency, not by bandwidth
-        for (int it0 = threadIdx.x >> 6; it0 < items; it0 += (kThreads / 64) * U) {
-            float4 val[U];
-            int dst[U], rx0[U];
+    __device__ __forceinline__ void setup(const unsigned char* xs_, int chunks_, int cb0, int n_total_, int h_, int w_, int imgs,
+                                          int lh_, int lw_) {
+        xs = xs_; chunks = chunks_; n_total = n_total_; h = h_; w = w_; lh = lh_; lw = lw_;
+        items = imgs * lh * lw * 16;
+        piece = threadIdx.x & 15;
+        chunk_ok = cb0 + (piece >> 3) < chunks;
+        lane_off = (int64_t)(cb0 + (piece >> 3)) * h * w * 128 + (piece & 7) * 16;   // (chunk-major rows)
+    }
+    __device__ __forceinline__ uint4 fetch(int e, int rx, int ry, int ri, bool& inside) const {
+        const int iy = iy0 + ry, ix = ix0 + rx, n = img0 + ri;
+        inside = e < items && iy >= 0 && iy < h && ix >= 0 && ix < w && n < n_total && chunk_ok;
+        // (no branch: a piece outside the tensor is read at the tensor's start and dropped)
+        return *reinterpret_cast<const uint4*>(xs + (inside ? (((int64_t)n * chunks * h + iy) * w + ix) * 128 + lane_off : 0));
+    }
+    __device__ __forceinline__ void load(int img0_, int iy0_, int ix0_) {
+        img0 = img0_; iy0 = iy0_; ix0 = ix0_;
+        // pixel of this lane's first piece; later pieces lie kThreads / 16 pixels further each
+        int rx = (threadIdx.x >> 4) % lw, ry = ((threadIdx.x >> 4) / lw) % lh, ri = (threadIdx.x >> 4) / (lw * lh);
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int it = it0 + u * (kThreads / 64);
-                const int v = it % nv;
-                const int r = it / nv;
-                const int ry = r % lh, ri = r / lh;
-                const int iy = iy0 + ry, n = img0 + ri, px0 = (vx0 + v) * 4;
-                val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const bool inside = it < items && iy >= 0 && iy < h && n < n_total && px0 >= 0 && px0 < w && c < c_total;
-                if (inside) val[u] = *reinterpret_cast<const float4*>(x + ((int64_t)n * c_total + c) * plane + (int64_t)iy * w + px0);
-                dst[u] = (it < items) ? ((ri * lh + ry) * lw) * kRowBytes + ch * 2 : -1;
-                rx0[u] = px0 - ix0;
-                float s = mul;
-                if (scale && inside) s *= scale[(int64_t)n * c_total + c];
-                val[u].x *= s; val[u].y *= s; val[u].z *= s; val[u].w *= s;
+        for (int u = 0; u < U; u++) {
+            val[u] = fetch(threadIdx.x + u * kThreads, rx, ry, ri, keep[u]);
+            rx += kThreads / 16;               // 16 pixels on: at most two rows (lw >= 8) and so at most two images
+#pragma unroll
+            for (int twice = 0; twice < 2; twice++) {
+                const int wrap = rx >= lw;
+                rx -= wrap ? lw : 0; ry += wrap;
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (dst[u] < 0) continue;
-                unsigned char* row = s_dst + dst[u];
-                const float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (rx0[u] + j >= 0 && rx0[u] + j < lw) store_split(row + (rx0[u] + j) * kRowBytes, e[j]);
+            for (int twice = 0; twice < 2; twice++) {
+                const int wrap = ry >= lh;
+                ry -= wrap ? lh : 0; ri += wrap;
             }
-        }
-    } else {
-        const int items = imgs * lh * lw;
-        for (int it = threadIdx.x >> 6; it < items; it += kThreads / 64) {
-            const int rx = it % lw;
-            const int r = it / lw;
-            const int ry = r % lh, ri = r / lh;
-            const int iy = iy0 + ry, ix = ix0 + rx, n = img0 + ri;
-            float val = 0.f;
-            if (iy >= 0 && iy < h && ix >= 0 && ix < w && n < n_total && c < c_total) {
-                val = x[((int64_t)n * c_total + c) * plane + (int64_t)iy * w + ix] * mul;
-                if (scale) val *= scale[(int64_t)n * c_total + c];
-            }
-            store_split(s_dst + (int64_t)it * kRowBytes + ch * 2, val);
         }
     }
-}
+    __device__ __forceinline__ void store(unsigned char* s_dst) const {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = threadIdx.x + u * kThreads;
+            const uint4 v = keep[u] ? val[u] : make_uint4(0, 0, 0, 0);
+            if (e < items) *reinterpret_cast<uint4*>(s_dst + (e >> 4) * kRowBytes + piece * 16) = v;
+        }
+        for (int e = threadIdx.x + U * kThreads; e < items; e += kThreads) {
+            const int pix = e >> 4;
+            bool inside;
+            const uint4 v = fetch(e, pix % lw, (pix / lw) % lh, pix / (lw * lh), inside);
+            *reinterpret_cast<uint4*>(s_dst + pix * kRowBytes + piece * 16) = inside ? v : make_uint4(0, 0, 0, 0);
+        }
+    }
+};
 
 // 4 pixel rows x 16 channels of halves, transposed: this lane's channel, the 4 rows in its elements.
 __device__ __forceinline__ f16x4_t read_tr(const unsigned char* p) {
@@ -125,8 +123,9 @@ __device__ __forceinline__ f16x8_t fragment(const unsigned char* first, const un
 }
 
 template <int NK>   // NK x NK taps
-__global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_params p, WTile t, int tiles_total, int x_vec,
-                                                                int g_vec, const unsigned* amax) {
+__global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_params p, WTile t, int tiles_total,
+                                                                const unsigned char* __restrict__ xs,
+                                                                const unsigned char* __restrict__ gs, const unsigned* amax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_x = smem;
     unsigned char* s_g = s_x + (size_t)t.imgs * t.lh * t.lw * kRowBytes;
@@ -134,12 +133,11 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int cg0 = blockIdx.y * BC, cx0 = blockIdx.z * BC;
     constexpr int MAX_TAPS = NK * NK;
-    const float* __restrict__ x = (const float*)p.x;
-    const float* __restrict__ g = (const float*)p.g;
+    const int chunks_x = (p.cx + 31) / 32, chunks_g = (p.cg + 31) / 32;
 
-    float mul_x, inv_x, mul_g, inv_g;
-    half_range_scale(amax, 0, 2, p.x_scale != nullptr, mul_x, inv_x);
-    half_range_scale(amax, 1, 3, p.g_scale != nullptr, mul_g, inv_g);
+    float mul, inv_x, inv_g;
+    half_range_scale(amax, 0, 2, p.x_scale != nullptr, mul, inv_x);
+    half_range_scale(amax, 1, 3, p.g_scale != nullptr, mul, inv_g);
 
     f32x4_t acc[MAX_TAPS][2][2];
 #pragma unroll
@@ -158,24 +156,43 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
         for (int j = 0; j < 2; j++) {
             const int kp = 16 * j + 4 * q + r;
             const int dr = kp / t.tw, dc = kp - dr * t.tw;
-            g_lane[j] = (dr * t.tw + dc) * kRowBytes + c4 * 8 + (wave >> 1) * 64;
-            x_lane[j] = (dr * p.step * t.lw + dc * p.step) * kRowBytes + c4 * 8 + (wave & 1) * 64;
+            g_lane[j] = (dr * t.tw + dc) * kRowBytes + c4 * 8 + (wave >> 1) * 128;   // (a wave's 32 channels: one chunk)
+            x_lane[j] = (dr * p.step * t.lw + dc * p.step) * kRowBytes + c4 * 8 + (wave & 1) * 128;
         }
     }
     const int rows_per_step = 32 / t.tw;
+    Stager<22> stage_x;   // (352 + 256 pixel rows in registers: the usual tiles whole)
+    Stager<16> stage_g;
+    stage_x.setup(xs, chunks_x, cx0 / 32, p.n, p.h, p.w_in, t.imgs, t.lh, t.lw);
+    stage_g.setup(gs, chunks_g, cg0 / 32, p.n, p.gh, p.gw, t.imgs, t.th, t.tw);
 
+#ifdef BAND_ABL_STAMPS
+    unsigned long long t_stage = 0, t_bar = 0, t_comp = 0, n_tiles = 0, t_begin = WSTAMP();
+#endif
     for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+#ifdef BAND_ABL_STAMPS
+        const unsigned long long s0 = WSTAMP();
+#endif
         int rest = tile;
         const int tb = rest % t.tiles_b; rest /= t.tiles_b;
         const int ta = rest % t.tiles_a; rest /= t.tiles_a;
         const int img0 = rest * t.imgs;
         const int a0 = ta * t.th, b0 = tb * t.tw;
         __syncthreads();
-        if (x_vec) stage<true>(s_x, x, p.x_scale, mul_x, p.n, p.cx, p.h, p.w_in, cx0, img0, t.imgs, a0 * p.step + p.dy0, b0 * p.step + p.dx0, t.lh, t.lw);
-        else stage<false>(s_x, x, p.x_scale, mul_x, p.n, p.cx, p.h, p.w_in, cx0, img0, t.imgs, a0 * p.step + p.dy0, b0 * p.step + p.dx0, t.lh, t.lw);
-        if (g_vec) stage<true>(s_g, g, p.g_scale, mul_g, p.n, p.cg, p.gh, p.gw, cg0, img0, t.imgs, a0, b0, t.th, t.tw);
-        else stage<false>(s_g, g, p.g_scale, mul_g, p.n, p.cg, p.gh, p.gw, cg0, img0, t.imgs, a0, b0, t.th, t.tw);
+#ifndef BAND_ABL_NOSTAGE
+        stage_x.load(img0, a0 * p.step + p.dy0, b0 * p.step + p.dx0);
+        stage_g.load(img0, a0, b0);
+        stage_x.store(s_x);
+        stage_g.store(s_g);
+#endif
+#ifdef BAND_ABL_STAMPS
+        const unsigned long long s1 = WSTAMP();
+#endif
         __syncthreads();
+#ifdef BAND_ABL_STAMPS
+        const unsigned long long s2 = WSTAMP();
+#endif
+#ifndef BAND_ABL_NOCOMPUTE
 
         for (int ri = 0; ri < t.imgs; ri++) {
             for (int ra = 0; ra < t.th; ra += rows_per_step) {
@@ -189,13 +206,13 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
                     for (int n = 0; n < 2; n++)
 #pragma unroll
                         for (int pl = 0; pl < 2; pl++)
-                            dst[n][pl] = fragment(xt + x_lane[0] + n * 32 + pl * 128, xt + x_lane[1] + n * 32 + pl * 128);
+                            dst[n][pl] = fragment(xt + x_lane[0] + n * 32 + pl * 64, xt + x_lane[1] + n * 32 + pl * 64);
                 };
 #pragma unroll
                 for (int m = 0; m < 2; m++)
 #pragma unroll
                     for (int pl = 0; pl < 2; pl++)
-                        a[m][pl] = fragment(gr + g_lane[0] + m * 32 + pl * 128, gr + g_lane[1] + m * 32 + pl * 128);
+                        a[m][pl] = fragment(gr + g_lane[0] + m * 32 + pl * 64, gr + g_lane[1] + m * 32 + pl * 64);
                 fetch_b(0, b);
 #pragma unroll
                 for (int tp = 0; tp < MAX_TAPS; tp++) {
@@ -220,7 +237,15 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
                 }
             }
         }
+#endif
+#ifdef BAND_ABL_STAMPS
+        const unsigned long long s3 = WSTAMP();
+        t_stage += s1 - s0; t_bar += s2 - s1; t_comp += s3 - s2; n_tiles++;
+#endif
     }
+#ifdef BAND_ABL_STAMPS
+    const unsigned long long t_loop = WSTAMP();
+#endif
 
     // ---- add into dw[tap][cg][cx]: lanes of a row run along cx ------------------------------------------------
     float* __restrict__ dw = p.dw;
@@ -236,6 +261,12 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
                     const int cx = cx0 + (wave & 1) * 32 + n * 16 + lrow;
                     if (cg < p.cg && cx < p.cx) atomicAdd(dw + ((int64_t)tp * p.cg + cg) * p.cx + cx, acc[tp][m][n][r] * inv_x * inv_g);
                 }
+#ifdef BAND_ABL_STAMPS
+    if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 1 && lane == 0) {
+        unsigned long long* o = wgrad_stamps[wave];
+        o[0] = t_stage; o[1] = t_bar; o[2] = t_comp; o[3] = n_tiles; o[4] = WSTAMP() - t_loop; o[5] = t_loop - t_begin;
+    }
+#endif
 }
 
 WTile make_wtile(const sg_conv2d_wgrad_params& p) {
@@ -279,13 +310,30 @@ int wgrad_f32_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
         if (e != hipSuccess) return fail((int)e, "conv2d_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     }
     const unsigned* amax = nullptr;
-    if (int rc = absmax_measure(stream, (const float*)p.x, (int64_t)p.n * p.cx * p.h * p.w_in, (const float*)p.g,
-                                (int64_t)p.n * p.cg * p.gh * p.gw, p.x_scale, (int64_t)p.n * p.cx, p.g_scale, (int64_t)p.n * p.cg, &amax))
+    const int64_t x_pixels = (int64_t)p.h * p.w_in, g_pixels = (int64_t)p.gh * p.gw;
+    if (int rc = absmax_measure(stream, (const float*)p.x, (int64_t)p.n * p.cx * x_pixels, (const float*)p.g,
+                                (int64_t)p.n * p.cg * g_pixels, p.x_scale, (int64_t)p.n * p.cx, p.g_scale, (int64_t)p.n * p.cg, &amax))
         return rc;
-    const int x_vec = (p.w_in % 4 == 0) && aligned16(p.x), g_vec = (p.gw % 4 == 0) && aligned16(p.g);
+    const size_t x_bytes = split_bytes((int64_t)p.n * x_pixels, p.cx), need = x_bytes + split_bytes((int64_t)p.n * g_pixels, p.cg);
+    unsigned char* work = (unsigned char*)p.workspace;
+    if (work != nullptr) {
+        SG_REQUIRE(p.workspace_bytes >= need && (reinterpret_cast<uintptr_t>(work) & 255u) == 0, SG_ERR_INVALID_ARGUMENT,
+                   "conv2d_wgrad: workspace of %zu bytes (need %zu, 256-byte aligned)", p.workspace_bytes, need);
+    } else {
+        work = (unsigned char*)split_workspace(stream, need);
+        if (work == nullptr) return (int)hipErrorOutOfMemory;
+    }
+    if (int rc = split_pixels(stream, (const float*)p.x, p.x_scale, p.n, p.cx, x_pixels, amax, 0, 2, work)) return rc;
+    if (int rc = split_pixels(stream, (const float*)p.g, p.g_scale, p.n, p.cg, g_pixels, amax, 1, 3, work + x_bytes)) return rc;
     hipLaunchKernelGGL(kernel, dim3((unsigned)split, (unsigned)blocks_g, (unsigned)blocks_x), dim3(kThreads), lds, stream, p, t,
-                       (int)tiles, x_vec, g_vec, amax);
+                       (int)tiles, (const unsigned char*)work, (const unsigned char*)(work + x_bytes), amax);
     return check_launch("sg_conv2d_wgrad (f32)");
 }
 
 }  // namespace sg
+
+#ifdef BAND_ABL_STAMPS
+extern "C" int sg_debug_wgrad_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sg::wgrad_stamps), sizeof(unsigned long long) * 64);
+}
+#endif

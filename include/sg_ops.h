@@ -15,6 +15,7 @@
 #ifndef SG_OPS_H
 #define SG_OPS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -232,9 +233,19 @@ typedef struct sg_conv2d_params {
      * kernels implement it: ask sg_conv2d_supports_mask() first; an unsupported call returns SG_ERR_UNSUPPORTED. */
     const void* mask_y;
     float mask_alpha, mask_clamp;
+    /* scratch memory in device memory, 256-byte aligned, of at least sg_conv2d_workspace_bytes(p) bytes; its contents
+     * mean nothing before or after the call.  Only float32 calls need any (they multiply copies of both operands cut
+     * into pairs of halves).  NULL with a non-zero requirement: the library uses a buffer of its own per device and
+     * stream, which it grows with hipMalloc when a call needs more - so such a call must not be recorded into a HIP
+     * graph, and the buffer stays allocated until the process ends. */
+    void* workspace;
+    size_t workspace_bytes;
 } sg_conv2d_params;
 
 int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
+
+/* Bytes of p->workspace the call needs (0: none).  Depends on dtype, n, ci, h, w_in, co and the phases only. */
+size_t sg_conv2d_workspace_bytes(const sg_conv2d_params* p);
 
 /* 1 when sg_conv2d honours p->mask_y for this geometry (decided as if mask_y were set), else 0. */
 int sg_conv2d_supports_mask(const sg_conv2d_params* p);
@@ -248,7 +259,8 @@ int sg_conv2d_reduce_rows(const sg_conv2d_params* p);
  * device, held until the process ends) instead of a caller-provided workspace, and are added up on the device:
  *   reduce_sum[n, co] (float32, written, not accumulated) = sum over pixels of reduce_x * contraction.
  * p->reduce_out must be NULL.  The call allocates and frees nothing; it is rejected with SG_ERR_UNSUPPORTED when
- * n * sg_conv2d_reduce_rows(p) * co exceeds the array.  Every call on a device shares that device's array: calls
+ * n * sg_conv2d_reduce_rows(p) * co exceeds the array, and with SG_ERR_INVALID_ARGUMENT when a float32 call comes
+ * without p->workspace (sg_conv2d_workspace_bytes(p) bytes: the scratch of the float32 kernels is the caller's here).  Every call on a device shares that device's array: calls
  * whose execution may overlap on one device (different streams) race; calls on one stream are safe. */
 #define SG_CONV2D_REDUCED_MAX_PARTIALS (1 << 20)
 int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t stream);
@@ -290,9 +302,15 @@ typedef struct sg_conv2d_wgrad_params {
      * kernel contracts g * m.  NULL = none.  Ask sg_conv2d_wgrad_supports_mask() first. */
     const void* mask_y;
     float mask_alpha, mask_clamp;
+    /* scratch memory as in sg_conv2d_params, at least sg_conv2d_wgrad_workspace_bytes(p) bytes */
+    void* workspace;
+    size_t workspace_bytes;
 } sg_conv2d_wgrad_params;
 
 int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stream);
+
+/* Bytes of p->workspace the call needs (0: none). */
+size_t sg_conv2d_wgrad_workspace_bytes(const sg_conv2d_wgrad_params* p);
 
 /* 1 when sg_conv2d_wgrad honours p->mask_y for this geometry (decided as if mask_y were set), else 0. */
 int sg_conv2d_wgrad_supports_mask(const sg_conv2d_wgrad_params* p);

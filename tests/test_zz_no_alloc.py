@@ -20,9 +20,12 @@ def _run(cp, n, ci, co, h, w, dtype, seed):
     y0, r0 = cp.conv2d(x, packed, plan, co, out_scale=s, reduce_x=rx)
     out = torch.full_like(y0, float('nan'))
     rsum = torch.full([n, co], float('nan'), device=DEV)
+    need = cp.workspace_bytes(x, plan, co)               # float32: the scratch of the half-split kernels is the caller's
+    assert (need > 0) == (dtype == torch.float32)
+    work = torch.empty([need], dtype=torch.uint8, device=DEV) if need else None
     torch.cuda.synchronize()
     before = torch.cuda.memory_stats()['allocation.all.allocated']
-    y1, r1 = cp.conv2d(x, packed, plan, co, out_scale=s, reduce_x=rx, out=out, reduce_sum=rsum)
+    y1, r1 = cp.conv2d(x, packed, plan, co, out_scale=s, reduce_x=rx, out=out, reduce_sum=rsum, workspace=work)
     assert torch.cuda.memory_stats()['allocation.all.allocated'] == before, 'the call allocated device memory through torch'
     assert y1 is out and r1 is rsum
     assert torch.equal(y1, y0)
@@ -56,3 +59,7 @@ def test_conv2d_reduced_rejects_oversize_and_bad_arguments():
     assert fn(ctypes.byref(p), None, None) == -3
     p.reduce_out = _lib.ptr(x)
     assert fn(ctypes.byref(p), _lib.ptr(x), None) == -1
+    p.reduce_out = None
+    p.dtype, p.n, p.h, p.w_in, p.oh, p.ow = 0, 1, 16, 16, 16, 16     # float32 without a workspace: refused, not allocated for
+    assert fn(ctypes.byref(p), _lib.ptr(x), None) == -1
+    assert b'allocates nothing' in _lib.lib().sg_last_error()

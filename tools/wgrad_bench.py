@@ -22,6 +22,7 @@ def timeit(fn, iters=10):
     return s.elapsed_time(e) / iters
 
 
+LAYERS += [(512, 512, 64, torch.float32), (512, 512, 32, torch.float32)]
 LAYERS += [(64, 128, -264, torch.bfloat16), (128, 256, -136, torch.bfloat16), (256, 512, -72, torch.bfloat16)]   # h < 0: stride 2, input h x h
 if os.environ.get('ONLY'):
     LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
