@@ -1081,6 +1081,7 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->g && p->dw, SG_ERR_NULL_POINTER, "conv2d_wgrad: x, g and dw must not be NULL");
     if (wgrad1x1_few_eligible(*p)) return wgrad1x1_few_launch(*p, (hipStream_t)stream);
+    if (wgrad_rows_eligible(*p)) return wgrad_rows_launch(*p, (hipStream_t)stream);
     SG_REQUIRE(p->mask_y == nullptr, SG_ERR_UNSUPPORTED, "conv2d_wgrad: no kernel applies a gradient mask for this geometry");
     if (wgrad3x3_eligible(*p)) return wgrad3x3_launch(*p, (hipStream_t)stream);
     if (wgrad_f32_eligible(*p)) return wgrad_f32_launch(*p, (hipStream_t)stream);
@@ -1126,7 +1127,7 @@ extern "C" int sg_conv2d_wgrad_supports_mask(const sg_conv2d_wgrad_params* p) {
     if (p == nullptr) return 0;
     sg_conv2d_wgrad_params q = *p;
     if (q.mask_y == nullptr) q.mask_y = q.g;
-    return sg::wgrad1x1_few_eligible(q) ? 1 : 0;
+    return (sg::wgrad1x1_few_eligible(q) || sg::wgrad_rows_eligible(q)) ? 1 : 0;
 }
 
 extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
@@ -1141,6 +1142,7 @@ extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
 extern "C" const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p) {
     if (p == nullptr) return "";
     if (sg::wgrad1x1_few_eligible(*p)) return "wgrad1x1_few_kernel";
+    if (sg::wgrad_rows_eligible(*p)) return "wgrad_rows_kernel";
     if (sg::wgrad3x3_eligible(*p)) return "wgrad3x3_kernel";
     return sg::wgrad_f32_eligible(*p) ? "wgrad_f32_kernel" : "conv2d_wgrad_kernel";
 }

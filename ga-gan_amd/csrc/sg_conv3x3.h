@@ -48,6 +48,10 @@ int conv_up2_launch(const sg_conv2d_params& p, hipStream_t stream);
 bool wgrad3x3_eligible(const sg_conv2d_wgrad_params& p);
 int wgrad3x3_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
 
+// Weight gradient of same-size 3x3 layers with 32 channels on both sides, with the activation mask (sg_wgrad_rows.hip).
+bool wgrad_rows_eligible(const sg_conv2d_wgrad_params& p);
+int wgrad_rows_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
+
 // Weight gradient of float32 layers with at least 32 channels on both sides (sg_wgrad_f32.hip).
 bool wgrad_f32_eligible(const sg_conv2d_wgrad_params& p);
 int wgrad_f32_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);

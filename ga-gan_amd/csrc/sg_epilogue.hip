@@ -33,12 +33,11 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(sg_epilogue_bwd_param
     const float inv_alpha = (ep.alpha != 0.f) ? 1.f / ep.alpha : 0.f;
     float sum_g = 0.f, sum_gv = 0.f, sum_gn = 0.f;
 
-    auto one = [&](float yv, float dyv, int i) -> float {
+    auto one = [&](float yv, float dyv, float noise) -> float {
         float g = dyv * ep.gain;
         if (ep.act == 3 && !(yv > 0.f)) g *= ep.alpha;
         if (ep.clamp >= 0.f && !(yv > -ep.clamp && yv < ep.clamp)) g = 0.f;
         sum_g += g;
-        const float noise = nz ? nz[i] : 0.f;
         if (p.dscale) {
             float t = yv * inv_gain;                       // act(pre-activation)
             if (ep.act == 3 && t < 0.f) t *= inv_alpha;    // pre-activation
@@ -50,17 +49,48 @@ __global__ void __launch_bounds__(256) epilogue_bwd_kernel(sg_epilogue_bwd_param
 
     const bool vec = (hw % VEC == 0) && aligned16(p.dy) && aligned16(p.y) && aligned16(p.dz);   // kSegment is a multiple of VEC
     if (vec) {
-        for (int k = seg0 / VEC + threadIdx.x; k < seg1 / VEC; k += blockDim.x) {
-            const Pack<T> vy = load_pack(y + k * VEC), vd = load_pack(dy + k * VEC);
+        // two packets per lane and step: both operands (and the noise row, as whole packets where its rows allow)
+        // are requested before either packet is worked on
+        const bool nz_vec = nz && (hw % 4 == 0) && ((reinterpret_cast<uintptr_t>(nz) & 15u) == 0) && VEC % 4 == 0;
+        auto noise_of = [&](int k, float (&out)[VEC]) {
+            if (nz_vec) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; q++) {
+                    const float4 v = *reinterpret_cast<const float4*>(nz + k * VEC + q * 4);
+                    out[q * 4] = v.x; out[q * 4 + 1] = v.y; out[q * 4 + 2] = v.z; out[q * 4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; j++) out[j] = nz ? nz[k * VEC + j] : 0.f;
+            }
+        };
+        auto packet = [&](int k, const Pack<T>& vy, const Pack<T>& vd, const float (&nv)[VEC]) {
             Pack<T> out;
 #pragma unroll
             for (int j = 0; j < VEC; j++)
-                out.v[j] = Elem<T>::store(one((float)Elem<T>::load(vy.v[j]), (float)Elem<T>::load(vd.v[j]), k * VEC + j));
+                out.v[j] = Elem<T>::store(one((float)Elem<T>::load(vy.v[j]), (float)Elem<T>::load(vd.v[j]), nv[j]));
             if (dz) store_pack(dz + k * VEC, out);
+        };
+        const int k1 = seg1 / VEC, step = blockDim.x;
+        int k = seg0 / VEC + threadIdx.x;
+        for (; k + step < k1; k += 2 * step) {
+            const Pack<T> vy0 = load_pack(y + k * VEC), vd0 = load_pack(dy + k * VEC);
+            const Pack<T> vy1 = load_pack(y + (k + step) * VEC), vd1 = load_pack(dy + (k + step) * VEC);
+            float n0[VEC], n1[VEC];
+            noise_of(k, n0);
+            noise_of(k + step, n1);
+            packet(k, vy0, vd0, n0);
+            packet(k + step, vy1, vd1, n1);
+        }
+        for (; k < k1; k += step) {
+            const Pack<T> vy = load_pack(y + k * VEC), vd = load_pack(dy + k * VEC);
+            float nv[VEC];
+            noise_of(k, nv);
+            packet(k, vy, vd, nv);
         }
     } else {
         for (int i = seg0 + threadIdx.x; i < seg1; i += blockDim.x) {
-            const T out = Elem<T>::store(one((float)Elem<T>::load(y[i]), (float)Elem<T>::load(dy[i]), i));
+            const T out = Elem<T>::store(one((float)Elem<T>::load(y[i]), (float)Elem<T>::load(dy[i]), nz ? nz[i] : 0.f));
             if (dz) dz[i] = out;
         }
     }

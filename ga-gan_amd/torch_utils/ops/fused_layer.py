@@ -133,9 +133,12 @@ class _FusedConv(torch.autograd.Function):
         want_ds = need[2] and styles is not None
         want_dx = need[0] or want_ds
         dy = dy.contiguous()
-        # The activation mask applied to dy while the kernels stage it: no dz tensor.  Taken when a masking kernel
-        # exists for every gradient that is wanted (data gradient, weight gradient) at this geometry.
-        if mode == 'same' and y is not None and (want_dx or need[1]):
+        # The activation mask applied to dy while the kernels stage it: no dz tensor.  Taken for 1x1 layers when a
+        # masking kernel exists for every gradient that is wanted (data gradient, weight gradient) at this geometry.
+        # (3x3 layers: the masking variants of the band and row kernels read dy and y and mask in registers beside
+        # their matrix instructions; writing dz once and reading it twice measured faster - 6.0 against 8.1 ms for
+        # the 32-channel layer at 1024 x 1024, 32 samples.)
+        if mode == 'same' and k == 1 and y is not None and (want_dx or need[1]):
             plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
             ok = not want_dx or (tuple(x.shape[2:]) == plan.out_size(*dy.shape[2:]) and _conv.supports_mask(dy, plan, ci, reduce=want_ds))
             ok = ok and (not need[1] or _conv.wgrad_supports_mask(x, dy, k, k, stride=stride, padding=padding))

@@ -128,3 +128,48 @@ def test_mask_is_refused_where_no_kernel_applies_it():
     assert not cp.supports_mask(x, plan, 48)
     with pytest.raises(RuntimeError, match='input mask'):
         cp.conv2d(x, plan.pack(torch.zeros([48, 48, 3, 3], device=DEV, dtype=torch.bfloat16)), plan, 48, mask_y=x)
+
+
+ROWS_CASES = [
+    # n, cx, cg, h, w, masked, scales
+    (2, 32, 32, 64, 64, False, True),
+    (2, 32, 32, 64, 128, True, True),
+    (1, 32, 32, 32, 64, True, False),
+    (3, 32, 32, 16, 64, False, False),
+    (2, 32, 32, 8, 192, True, True),
+    (33, 32, 32, 4, 64, True, True),      # more tiles than one XCD's share of workgroups, ragged shares
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('case', ROWS_CASES, ids=[f'r{i}' for i in range(len(ROWS_CASES))])
+def test_weight_gradient_of_narrow_same_size_layers(case, dtype):
+    """wgrad_rows_kernel (3x3, unit stride, 32 channels, rows of whole 64-pixel tiles) with and without the
+    activation mask on the gradient operand, against float64 arithmetic on the operands as the kernel rounds them
+    (g * scale * mask and x * scale, to the 16-bit type, as the kernels it replaces do): 1e-5 relative L2, the float32
+    accumulation."""
+    from ga_gan_amd import conv2d_plugin as cp
+    n, cx, cg, h, w, masked, scales = case
+    gen = torch.Generator(device='cuda').manual_seed(h * 7 + w)
+    x = torch.randn([n, cx, h, w], device='cuda', generator=gen).to(dtype)
+    g = torch.randn([n, cg, h, w], device='cuda', generator=gen).to(dtype)
+    y = (torch.randn([n, cg, h, w], device='cuda', generator=gen) * 2).to(dtype)
+    xs = (1 + 0.3 * torch.randn([n, cx], device='cuda', generator=gen)) if scales else None
+    gs = (1 + 0.3 * torch.rand([n, cg], device='cuda', generator=gen)) if scales else None
+    p = cp._wgrad_params(x, g, 3, 3, 1, 1, xs, gs, None, y if masked else None, 0.2, 1.5)
+    import ctypes
+    from ga_gan_amd import _lib
+    assert _lib.lib().sg_conv2d_wgrad_kernel(ctypes.byref(p)) == b'wgrad_rows_kernel'
+    assert cp.wgrad_supports_mask(x, g, 3, 3, 1, 1)
+    kw = dict(mask_y=y, mask_alpha=0.2, mask_clamp=1.5) if masked else {}
+    dw = cp.conv2d_wgrad(x, g, 3, 3, stride=1, padding=1, x_scale=xs, g_scale=gs, **kw)
+    gf, xf = g.float(), x.float()                 # the kernel's own order: scale, mask, round to the 16-bit type
+    if scales:
+        gf = gf * gs.reshape(n, cg, 1, 1)
+        xf = xf * xs.reshape(n, cx, 1, 1)
+    if masked:
+        gf = gf * torch.where(y > 0, 1.0, 0.2).float() * (y.abs() < 1.5).float()
+    gd, xd = gf.to(dtype).double(), xf.to(dtype).double()
+    want = torch.nn.grad.conv2d_weight(xd.cpu(), (cg, cx, 3, 3), gd.cpu(), padding=1)
+    err = float((dw.double().cpu() - want).norm() / want.norm())
+    assert err < 1e-5, err

@@ -23,7 +23,9 @@ def timeit(fn, iters=10):
 
 
 LAYERS += [(512, 512, 64, torch.float32), (512, 512, 32, torch.float32)]
-LAYERS += [(64, 128, -264, torch.bfloat16), (128, 256, -136, torch.bfloat16), (256, 512, -72, torch.bfloat16)]   # h < 0: stride 2, input h x h
+LAYERS += [(32, 32, 1024, torch.bfloat16), (64, 64, 512, torch.bfloat16)]   # 8, 9
+LAYERS_STRIDED = [(64, 128, -264, torch.bfloat16), (128, 256, -136, torch.bfloat16), (256, 512, -72, torch.bfloat16)]   # h < 0: stride 2, input h x h
+LAYERS += LAYERS_STRIDED
 if os.environ.get('ONLY'):
     LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
 for ci, co, h, dtype in LAYERS:
