@@ -16,7 +16,7 @@ SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d
            'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad', 'sg_upfirdn2d_epilogue',
            'sg_epilogue_backward', 'sg_conv2d_reduce_rows', 'sg_conv2d_kernel', 'sg_conv2d_wgrad_kernel',
            'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask',
-           'sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes')
+           'sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes', 'sg_conv_up2_fir', 'sg_conv_up2_fir_supported')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -74,7 +74,9 @@ def lib():
             getattr(handle, name).restype = ctypes.c_int
         handle.sg_conv2d_reduced.argtypes = [vp, vp, vp]
         handle.sg_conv2d_reduced.restype = ctypes.c_int
-        for name in ('sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask'):
+        handle.sg_conv_up2_fir.argtypes = [vp, vp]
+        handle.sg_conv_up2_fir.restype = ctypes.c_int
+        for name in ('sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask', 'sg_conv_up2_fir_supported'):
             getattr(handle, name).argtypes = [vp]
             getattr(handle, name).restype = ctypes.c_int
         for name in ('sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes'):

@@ -21,9 +21,9 @@ OUT = os.path.join(HERE, 'libsgops.so')
 OBJ_DIR = os.path.join(HERE, 'build')
 CFLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
           '-Wno-unused-const-variable']
-# per-source additions.  The band kernel's epilogue runs beside matrix instructions, where packed float32 vector
+# per-source additions.  The epilogues of the band and one-pass up-sampling kernels run beside matrix instructions, where packed float32 vector
 # instructions (what the SLP vectoriser makes of adjacent scalar multiplies) cost more than the two scalar ones.
-EXTRA_CFLAGS = {'sg_band3x3': ['-fno-slp-vectorize']}
+EXTRA_CFLAGS = {'sg_band3x3': ['-fno-slp-vectorize'], 'sg_convup_fir': ['-fno-slp-vectorize']}
 
 
 def sources():

@@ -1,7 +1,8 @@
 """Bindings of the layer-epilogue entry points (include/sg_ops.h): `sg_upfirdn2d_epilogue`
-(blur with the demodulation / noise / bias / activation epilogue in the same pass) and
+(blur with the demodulation / noise / bias / activation epilogue in the same pass),
 `sg_epilogue_backward` (gradient through that epilogue plus the bias, scale and noise-strength
-reductions in one pass over dy and y)."""
+reductions in one pass over dy and y) and `sg_conv_up2_fir` (a whole up-sampling layer -
+transposed convolution, resampling filter, epilogue - in one pass)."""
 import ctypes
 
 import torch
@@ -86,3 +87,72 @@ def epilogue_backward(dy, y, want_dbias, want_dscale, want_dnoise_gain, want_dz=
                               dscale=_lib.ptr(dscale), dnoise_gain=_lib.ptr(dng), dtype=_lib.dtype_code(y), n=n, c=c, h=h, w=w)
         _lib.launch('sg_epilogue_backward', p, y, 'epilogue_bwd_kernel', _lib.nbytes(dy, y, dz))
     return dz, dbias, dscale, dng
+
+
+class ConvUp2FirParams(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p), ('in_scale', ctypes.c_void_p),
+                ('fy4', ctypes.c_void_p), ('ep', Epilogue), ('dtype', ctypes.c_int32), ('n', ctypes.c_int32),
+                ('ci', ctypes.c_int32), ('h', ctypes.c_int32), ('w_in', ctypes.c_int32), ('co', ctypes.c_int32)]
+
+
+def separable_taps(f):
+    """(m, fy4) for a 4 x 4 float32 filter of rank one, f = outer(fy, fx), else None: m [3, 6] maps a weight row
+    (3 taps kx) to its convolution with 2 * fx (6 taps d = kx - j + 1 for filter tap fx[3 - j]) in the column order
+    d = -2, 0, 2, -1, 1, 3 of `sg_conv_up2_fir`; fy4 holds 2 * fy[3 - i].  Both stay on the device.  The rank check
+    reads the filter back once: callers cache the answer per filter tensor."""
+    if f is None or f.dim() != 2 or tuple(f.shape) != (4, 4) or f.dtype != torch.float32:
+        return None
+    total = f.sum()
+    fy, fx = f.sum(dim=1), f.sum(dim=0) / total
+    if not bool(torch.isfinite(fx).all()) or not torch.allclose(torch.outer(fy, fx), f, rtol=1e-5, atol=1e-7):
+        return None
+    m = f.new_zeros([3, 6])
+    for kx in range(3):
+        m[kx, kx:kx + 4] = 2.0 * fx          # column d + 2 = kx + (3 - j)
+    m = torch.cat([m[:, 0::2], m[:, 1::2]], dim=1).contiguous()
+    return m, (2.0 * fy.flip(0)).contiguous()
+
+
+def compose_up2_weights(w, m):
+    """Weights of `conv_up2_fir`: every row of w [co, ci, 3, 3] (the kernel of the stride-2 transposed convolution,
+    t[2a+ky, 2b+kx] += x[a, b] * w[ky, kx]) convolved with the horizontal half of the resampling filter and its share
+    of the gain (`m` of `separable_taps`), laid out [row tap: ky 0, 2, 1][column tap][co][ci] in w's dtype."""
+    full = torch.matmul(w.to(torch.float32), m)            # [co, ci, ky, column tap]
+    rows = torch.cat([full[:, :, 0:1], full[:, :, 2:3], full[:, :, 1:2]], dim=2)
+    return rows.permute(2, 3, 0, 1).contiguous().to(w.dtype)
+
+
+def _up2_fir_params(x, w_fir, y, fy4, co, in_scale, ep):
+    n, ci, h, w_in = x.shape
+    return ConvUp2FirParams(x=_lib.ptr(x), w=_lib.ptr(w_fir), y=_lib.ptr(y), in_scale=_lib.ptr(in_scale), fy4=_lib.ptr(fy4), ep=ep,
+                            dtype=_lib.dtype_code(x), n=n, ci=ci, h=h, w_in=w_in, co=co)
+
+
+def conv_up2_fir_supported(x, co, act='linear', alpha=0.2, gain=1.0):
+    """True when `conv_up2_fir` has a kernel for x [n, ci, h, w] -> [n, co, 2h, 2w] (16-bit, dense, aligned)."""
+    if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float16, torch.bfloat16):
+        return False
+    ep = Epilogue(act=ACT_INDEX[act], alpha=alpha, gain=gain, clamp=-1.0)
+    p = _up2_fir_params(x, x, x, x, co, None, ep)
+    return bool(_lib.lib().sg_conv_up2_fir_supported(ctypes.byref(p)))
+
+
+def conv_up2_fir(x, w_fir, co, fy4, in_scale=None, **epilogue):
+    """epilogue(upfirdn2d(conv_transpose2d(x * in_scale, w, stride 2), f, padding 1, gain 4)) in one kernel.
+    (m, fy4) = separable_taps(f); w_fir = compose_up2_weights(w, m)."""
+    if not x.is_cuda or x.dim() != 4 or not x.is_contiguous():
+        raise RuntimeError('x must be a dense NCHW tensor on the GPU')
+    n, ci, h, w_in = x.shape
+    if w_fir.dtype != x.dtype or w_fir.numel() != 18 * co * ci or not w_fir.is_contiguous():
+        raise RuntimeError('composed weights must be dense [3, 6, co, ci] of x\'s dtype')
+    if fy4.dtype != torch.float32 or fy4.numel() != 4 or not fy4.is_contiguous():
+        raise RuntimeError('fy4 must hold four float32 values')
+    if in_scale is not None and (in_scale.dtype != torch.float32 or tuple(in_scale.shape) != (n, ci) or not in_scale.is_contiguous()):
+        raise RuntimeError(f'in_scale must be a dense float32 tensor of shape {(n, ci)}')
+    y = torch.empty([n, co, 2 * h, 2 * w_in], dtype=x.dtype, device=x.device)
+    ep = make_epilogue(n, co, 2 * h, 2 * w_in, x.dtype, **epilogue)
+    p = _up2_fir_params(x, w_fir, y, fy4, co, in_scale, ep)
+    flops = 2.0 * n * ci * co * 18 * h * w_in
+    _lib.launch('sg_conv_up2_fir', p, x, f'conv_up2_fir_kernel<{"__hip_bfloat16" if x.dtype == torch.bfloat16 else "__half"}>',
+                _lib.nbytes(x, y), flops=flops)
+    return y

@@ -9,6 +9,8 @@ discriminator `Conv2dLayer` (:748-760) without their intermediate tensors.  When
 higher-order graph is being recorded (path-length and R1 regularisation) the backward re-expresses
 the layer with the differentiable primitive ops instead, so gradients of any order stay available.
 """
+import weakref
+
 import torch
 
 from ... import conv2d_plugin as _conv
@@ -24,6 +26,7 @@ from .upfirdn2d import _get_filter_size
 
 
 MIN_FUSED_PIXELS_F32 = 1 << 15
+ONE_PASS_UP_MAX_CHANNELS = 128
 
 
 def supported(x, w, up, down, groups=1):
@@ -42,6 +45,36 @@ def supported(x, w, up, down, groups=1):
 
 def _flipped(w):
     return memo.memo(w, 'flip', lambda: w.flip([2, 3]))
+
+
+_FILTER_TAPS = {}   # id(filter tensor) -> (weak reference, version, separable_taps(filter))
+
+
+def _filter_taps(f):
+    hit = _FILTER_TAPS.get(id(f))
+    if hit is not None and hit[0]() is f and hit[1] == f._version:
+        return hit[2]
+    if f.is_cuda and torch.cuda.is_current_stream_capturing():
+        return None     # the rank check reads the filter back: not while a graph is being recorded
+    value = _layer.separable_taps(f)
+    _FILTER_TAPS[id(f)] = (weakref.ref(f, lambda _, key=id(f): _FILTER_TAPS.pop(key, None)), f._version, value)
+    return value
+
+
+def _one_pass_up(x, w, f, k, blur_pad, extra, act, alpha, gain):
+    """(composed weights, vertical taps) when the one-pass kernel covers this up-sampling layer, else None."""
+    # Beyond 128 input channels the layer is bound by its matrix work, which the one-pass form doubles (18 tap
+    # combinations instead of 9): there the two passes are faster (256 -> 128 channels at 128^2, 32 samples: 1.08 ms
+    # against 1.20 ms; 128 -> 64 at 256^2: 1.58 against 1.36; 64 -> 32 at 512^2: 2.88 against 1.54).
+    if x.shape[1] > ONE_PASS_UP_MAX_CHANNELS:
+        return None
+    if k != 3 or tuple(blur_pad) != (1, 1 - extra, 1, 1) or not _layer.conv_up2_fir_supported(x, w.shape[0], act, alpha, gain):
+        return None
+    taps = _filter_taps(f)
+    if taps is None:
+        return None
+    m, fy4 = taps
+    return memo.memo(w, 'up2_fir', lambda: _layer.compose_up2_weights(w, m)), fy4
 
 
 def _noise_plane(noise, dtype):
@@ -89,9 +122,13 @@ class _FusedConv(torch.autograd.Function):
         else:
             plan = _conv.plan_conv_transpose(k, k, stride=2, padding=0)
             th, tw = plan.out_size(x.shape[2], x.shape[3])
-            t = _conv.conv2d(x, plan.pack(w), plan, co, in_scale=styles, out_hw=(th, tw + extra))
-            y = _layer.blur_epilogue(t, f, blur_pad, False, 4.0, scale=dcoefs, **ep)
-            ctx.t_shape = t.shape
+            ctx.t_shape = (x.shape[0], co, th, tw + extra)
+            fir = _one_pass_up(x, w, f, k, blur_pad, extra, act, alpha, gain)
+            if fir is not None:     # transposed convolution, filter and epilogue in one kernel, no intermediate
+                y = _layer.conv_up2_fir(x, fir[0], co, fir[1], in_scale=styles, scale=dcoefs, **ep)
+            else:
+                t = _conv.conv2d(x, plan.pack(w), plan, co, in_scale=styles, out_hw=(th, tw + extra))
+                y = _layer.blur_epilogue(t, f, blur_pad, False, 4.0, scale=dcoefs, **ep)
         # the output is only needed where the backward reads it: activation slope, clamp mask, demodulation
         # gradient; a linear, unclamped layer (the residual skips) may then be updated in place by its caller
         keep_y = act != 'linear' or clamp >= 0 or dcoefs is not None

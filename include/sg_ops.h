@@ -276,6 +276,36 @@ int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t 
 const char* sg_conv2d_kernel(const sg_conv2d_params* p);
 
 /* ---------------------------------------------------------------------------
+ * conv_up2_fir: an up-sampling 3x3 layer in one pass, with no intermediate tensor:
+ *   t = conv_transpose2d(x * in_scale, W, stride 2)            [n, co, 2h+1, 2w+1]
+ *   u = upfirdn2d(t, f, padding 1 on every side, gain 4)       [n, co, 2h, 2w],  f = fy (x) fx separable, 4 taps
+ *   y = epilogue(u)                                            (sg_epilogue: demodulation, noise, bias, act, gain, clamp)
+ * i.e. the `up=2` branch of torch_utils/ops/conv2d_resample.py:125-142 (transposed convolution, then the resampling
+ * filter with gain up^2) as called by `modulated_conv2d` (training/networks.py:640-653), with the `bias_act` that
+ * follows it (training/networks.py:919-921).  The horizontal filter is folded into the weights by the caller:
+ *   w [3][6][co][ci] (dtype), w[r][c] = sum over (kx, j) with kx - j + 1 == D[c] of 2 * fx[3 - j] * W[co, ci, KY[r], kx],
+ *   KY = {0, 2, 1}, D = {-2, 0, 2, -1, 1, 3}                  (W[co, ci, ky, kx]: t[2a+ky, 2b+kx] += x[a, b] * W)
+ * and the vertical one runs on the accumulators: fy4 = device array of the 4 values 2 * fy[3 - i], i = 0..3, that
+ * multiply rows oy - 1 + i of t for output row oy.  x [n, ci, h, w_in] and y [n, co, 2h, 2w_in] are dense NCHW of
+ * `dtype` (f16 or bf16); in_scale [n, ci] float32 or NULL.  Geometries outside sg_conv_up2_fir_supported()
+ * (16-byte aligned tensors, ci % 8 == 0, ci >= 32, w_in % 8 == 0, w_in >= 32, h >= 2, gain > 0, 0 <= alpha <= 1)
+ * return SG_ERR_UNSUPPORTED: compose the layer from sg_conv2d and sg_upfirdn2d_epilogue instead.
+ */
+typedef struct sg_conv_up2_fir_params {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* in_scale;
+    const float* fy4;
+    sg_epilogue ep;
+    int32_t dtype;
+    int32_t n, ci, h, w_in, co;
+} sg_conv_up2_fir_params;
+
+int sg_conv_up2_fir(const sg_conv_up2_fir_params* p, sg_stream_t stream);
+int sg_conv_up2_fir_supported(const sg_conv_up2_fir_params* p);
+
+/* ---------------------------------------------------------------------------
  * conv2d_wgrad: weight gradient of the convolution above (one phase),
  *   dw[ky][kx][cg][cx] += sum_{n,a,b} g[n,cg,a,b] * g_scale[n,cg]
  *                                     * x[n,cx,a*step+dy0+ky,b*step+dx0+kx] * x_scale[n,cx]

@@ -35,6 +35,11 @@ CASES = [
     (5, 20, 72, 8, 3, 1, 1, True, True, 'lrelu', None),        # ragged channel counts
     (2, 96, 80, 32, 3, 1, 1, True, True, 'lrelu', 256.0),      # wide layer: the 3x3 unit-stride kernels, forward and both gradients
     (2, 72, 136, 40, 3, 1, 1, True, False, 'linear', None),
+    # up-sampling layers of the one-pass kernel (transposed convolution + filter + epilogue):
+    (2, 64, 32, 64, 3, 2, 1, True, True, 'lrelu', 256.0),      # whole composed kernel resident in LDS, two channel chunks
+    (1, 32, 16, 40, 3, 2, 1, True, True, 'lrelu', 256.0),      # one chunk, ragged width, half a channel group
+    (2, 96, 48, 72, 3, 2, 1, True, False, 'linear', None),     # streamed weights, two channel groups, ragged tiles
+    (1, 128, 64, 32, 3, 2, 1, False, True, 'lrelu', 256.0),    # narrow rows, four chunks, no modulation
 ]
 
 
