@@ -15,6 +15,7 @@
 // floor(mid / up), first tap (in + 1) * up - mid - 1 of the flipped filter, then every
 // up-th tap.
 #include "sg_common.h"
+#include "sg_upfirdn2d.h"
 
 namespace sg {
 namespace {
@@ -352,6 +353,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
 
 template <class T>
 int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream, const sg_epilogue* ep = nullptr) {
+    if (blur_stream_eligible(p, ep)) return blur_stream_launch(p, ep, stream);
     const int tiles_x = (p.out_w + 63) / 64, tiles_y = (p.out_h + 31) / 32;
     const int64_t planes = (int64_t)p.in_n * p.in_c, tiles = (int64_t)tiles_x * tiles_y;
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");

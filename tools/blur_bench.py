@@ -15,7 +15,7 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters
 
 f = U.setup_filter([1, 3, 3, 1], device='cuda')
-for (n, c, h, w, pads, dt) in ((32, 64, 257, 264, (1, -6, 1, 1), torch.bfloat16), (32, 128, 129, 136, (1, -6, 1, 1), torch.bfloat16),
+for (n, c, h, w, pads, dt) in ((32, 32, 1025, 1032, (1, -6, 1, 1), torch.bfloat16), (16, 32, 1024, 1024, (2, 9, 2, 2), torch.bfloat16), (32, 64, 257, 264, (1, -6, 1, 1), torch.bfloat16), (32, 128, 129, 136, (1, -6, 1, 1), torch.bfloat16),
                                (32, 64, 256, 256, (2, 9, 2, 2), torch.bfloat16), (32, 256, 65, 72, (1, -6, 1, 1), torch.bfloat16),
                                (32, 512, 17, 24, (1, -6, 1, 1), torch.float32)):
     x = torch.randn(n, c, h, w, device='cuda').to(dt)
