@@ -201,6 +201,315 @@ __global__ void __launch_bounds__(256) blur4_stream_kernel(sg_upfirdn2d_params p
     }
 }
 
+// The same walk for down-sampling by two (up = 1, down = 2: the filter in front of the discriminator's 1x1 skip
+// convolutions): a lane's 8 output columns read 16 input columns (two packets per plane plus 8 bytes on either side),
+// an input row feeds two output rows (its filter rows i with 2 o + i - pad = row), and two partial rows rotate.
+struct Row2 {
+    uint2 l[2];
+    uint4 m[2][2];
+    uint2 r[2];
+};
+
+template <class T, int PADX>
+__global__ void __launch_bounds__(256) down2_stream_kernel(sg_upfirdn2d_params p, int col0, int col_end, int lpr, int cblocks, int bands, int units) {
+    const int lane = threadIdx.x & 63;
+    const int wave_unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int sub = lane / lpr, unit = wave_unit * (64 / lpr) + sub;
+    const bool live = sub < 64 / lpr && unit < units;
+    const int cb = unit % cblocks, bd = (unit / cblocks) % bands, pp = live ? unit / (cblocks * bands) : 0;
+    const int planes = p.in_n * p.in_c;
+    const int pl0 = 2 * pp, pl1 = min(2 * pp + 1, planes - 1);
+    const bool second = 2 * pp + 1 < planes;
+    const int n0 = pl0 / p.in_c, c0 = pl0 - n0 * p.in_c, n1 = pl1 / p.in_c, c1 = pl1 - n1 * p.in_c;
+    const T* __restrict__ x0 = (const T*)p.x + (int64_t)n0 * p.in_stride_n + (int64_t)c0 * p.in_stride_c;
+    const T* __restrict__ x1 = (const T*)p.x + (int64_t)n1 * p.in_stride_n + (int64_t)c1 * p.in_stride_c;
+    T* __restrict__ y0 = (T*)p.y + (int64_t)n0 * p.out_stride_n + (int64_t)c0 * p.out_stride_c;
+    T* __restrict__ y1 = (T*)p.y + (int64_t)n1 * p.out_stride_n + (int64_t)c1 * p.out_stride_c;
+    const int ox0 = col0 + cb * kCols + (lane - sub * lpr) * 8, oy0 = bd * kBand;
+    const int rows = live ? min(kBand, p.out_h - oy0) : -1;        // (a dead lane loads and stores nothing)
+    const bool col_ok = ox0 < col_end;
+
+    float f[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float v = 0.f;
+            if (t < p.f_w && i < p.f_h) {
+                const int sx = p.flip ? t : p.f_w - 1 - t, sy = p.flip ? i : p.f_h - 1 - i;
+                v = p.f[(int64_t)sx * p.f_stride_w + (int64_t)sy * p.f_stride_h] * p.gain;
+            }
+            f[i][t] = v;
+        }
+
+    // in[e] is input column 2 ox0 - 4 + e; output column j, tap t reads column 2 (ox0 + j) - pad_x0 + t
+    const int ix_main = 2 * ox0;
+    auto load_row = [&](int k, Row2& row) __attribute__((always_inline)) {
+        const int iy = 2 * oy0 - p.pad_y0 + k;
+        const bool row_ok = iy >= 0 && iy < p.in_h && k < 2 * rows + 2 && col_ok;
+        const bool m0_ok = row_ok && ix_main < p.in_w, m1_ok = row_ok && ix_main + 8 < p.in_w,
+                   l_ok = row_ok && ix_main >= 8 && ix_main - 4 < p.in_w, r_ok = row_ok && ix_main + 16 < p.in_w;
+        const int64_t off = (int64_t)iy * p.in_stride_h + ix_main;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const T* src = (q ? x1 : x0) + off;
+            row.m[q][0] = m0_ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+            row.m[q][1] = m1_ok ? *reinterpret_cast<const uint4*>(src + 8) : make_uint4(0, 0, 0, 0);
+            row.l[q] = l_ok ? *reinterpret_cast<const uint2*>(src - 4) : make_uint2(0, 0);
+            row.r[q] = r_ok ? *reinterpret_cast<const uint2*>(src + 16) : make_uint2(0, 0);
+        }
+    };
+
+    f32x2_t acc[2][8];
+    // input row k (k & 3 == s): filter rows i = (k & 1), (k & 1) + 2 feed output rows (k - i) / 2; slot = output row & 1
+    auto consume = [&](int k, int s, const Row2& row) __attribute__((always_inline)) {
+        f32x2_t in[24];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const unsigned a = j ? row.l[0].y : row.l[0].x, b = j ? row.l[1].y : row.l[1].x;
+            in[2 * j] = f32x2_t{Pair<T>::lo(a), Pair<T>::lo(b)};
+            in[2 * j + 1] = f32x2_t{Pair<T>::hi(a), Pair<T>::hi(b)};
+            const unsigned c = j ? row.r[0].y : row.r[0].x, d = j ? row.r[1].y : row.r[1].x;
+            in[20 + 2 * j] = f32x2_t{Pair<T>::lo(c), Pair<T>::lo(d)};
+            in[20 + 2 * j + 1] = f32x2_t{Pair<T>::hi(c), Pair<T>::hi(d)};
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned ma[4] = {row.m[0][h].x, row.m[0][h].y, row.m[0][h].z, row.m[0][h].w};
+            const unsigned mb[4] = {row.m[1][h].x, row.m[1][h].y, row.m[1][h].z, row.m[1][h].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                in[4 + 8 * h + 2 * j] = f32x2_t{Pair<T>::lo(ma[j]), Pair<T>::lo(mb[j])};
+                in[4 + 8 * h + 2 * j + 1] = f32x2_t{Pair<T>::hi(ma[j]), Pair<T>::hi(mb[j])};
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            const int i = (s & 1) + 2 * ii;
+            const int slot = ((s - i) >> 1) & 1;       // (k - i) / 2 mod 2 with k = 4 m + s
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                f32x2_t v = i == 0 ? f32x2_t{0.f, 0.f} : acc[slot][j];
+#pragma unroll
+                for (int t = 0; t < 4; t++) v = __builtin_elementwise_fma(f32x2_t{f[i][t], f[i][t]}, in[4 - PADX + 2 * j + t], v);
+                acc[slot][j] = v;
+            }
+        }
+        if (s & 1) {                                   // filter row 3 completes output row (k - 3) / 2
+            const int o = (k - 3) >> 1, slot = ((s - 3) >> 1) & 1;
+            if (o >= 0 && o < rows && col_ok) {
+                const int64_t off = (int64_t)(oy0 + o) * p.out_stride_h + ox0;
+                *reinterpret_cast<uint4*>(y0 + off) = make_uint4(Pair<T>::pack(acc[slot][0][0], acc[slot][1][0]), Pair<T>::pack(acc[slot][2][0], acc[slot][3][0]),
+                                                                 Pair<T>::pack(acc[slot][4][0], acc[slot][5][0]), Pair<T>::pack(acc[slot][6][0], acc[slot][7][0]));
+                if (second)
+                    *reinterpret_cast<uint4*>(y1 + off) = make_uint4(Pair<T>::pack(acc[slot][0][1], acc[slot][1][1]), Pair<T>::pack(acc[slot][2][1], acc[slot][3][1]),
+                                                                     Pair<T>::pack(acc[slot][4][1], acc[slot][5][1]), Pair<T>::pack(acc[slot][6][1], acc[slot][7][1]));
+            }
+        }
+    };
+
+    Row2 ra, rb;
+    load_row(0, ra);
+    load_row(1, rb);
+    const int total = 2 * min(kBand, p.out_h) + 2;
+    for (int k0 = 0; k0 < total; k0 += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int k = k0 + s;
+            Row2 cur = (s & 1) ? rb : ra;
+            load_row(k + 2, (s & 1) ? rb : ra);
+            consume(k, s, cur);
+        }
+    }
+}
+
+template <class T, int PADX>
+int launch_down2_columns(const sg_upfirdn2d_params& p, int col0, int col_end, hipStream_t stream) {
+    const int width = col_end - col0;
+    const int cblocks = (width + kCols - 1) / kCols, bands = (p.out_h + kBand - 1) / kBand;
+    const int lpr = cblocks > 1 ? 64 : width / 8;
+    const int64_t pairs = ((int64_t)p.in_n * p.in_c + 1) / 2;
+    const int64_t units = pairs * cblocks * bands;
+    SG_REQUIRE(units <= INT32_MAX / 2, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
+    const int64_t waves = (units + 64 / lpr - 1) / (64 / lpr);
+    hipLaunchKernelGGL((down2_stream_kernel<T, PADX>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p, col0, col_end, lpr,
+                       cblocks, bands, (int)units);
+    return check_launch("sg_upfirdn2d (down-sampling stream)");
+}
+
+template <class T, int PADX>
+int launch_down2(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    const int packets = p.out_w / 8;
+    const int head = packets > 64 ? packets / 64 * 64 : packets;
+    int rc = launch_down2_columns<T, PADX>(p, 0, head * 8, stream);
+    if (rc == SG_OK && head < packets) rc = launch_down2_columns<T, PADX>(p, head * 8, p.out_w, stream);
+    return rc;
+}
+
+template <class T>
+int launch_down2_pad(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    switch (p.pad_x0) {
+        case 0: return launch_down2<T, 0>(p, stream);
+        case 1: return launch_down2<T, 1>(p, stream);
+        case 2: return launch_down2<T, 2>(p, stream);
+        default: return launch_down2<T, 3>(p, stream);
+    }
+}
+
+// And for up-sampling by two (up = 2, down = 1: the adjoint of the filter above, and the image up-sampling of 16-bit
+// tensors).  Only every other row and column of the zero-stuffed plane is non-zero, so an output reads 2 x 2 taps: a
+// lane's 16 output columns read one packet per plane plus one element on either side (loaded as 8 bytes), and input
+// row r completes the output rows e = 2r - 3, 2r - 2 (its filter rows 3 and 2 on top of what row r - 1 left) and
+// starts the rows 2r - 1, 2r (filter rows 1 and 0), with e = output row - pad_y0.  No rotation, 2 packed
+// multiply-adds per output.
+template <class T, int PADX>
+__global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, int lpr, int cblocks, int bands, int units) {
+    constexpr int kColsUp = 1024;                 // 16 output columns per lane
+    const int lane = threadIdx.x & 63;
+    const int wave_unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int sub = lane / lpr, unit = wave_unit * (64 / lpr) + sub;
+    const bool live = sub < 64 / lpr && unit < units;
+    const int cb = unit % cblocks, bd = (unit / cblocks) % bands, pp = live ? unit / (cblocks * bands) : 0;
+    const int planes = p.in_n * p.in_c;
+    const int pl0 = 2 * pp, pl1 = min(2 * pp + 1, planes - 1);
+    const bool second = 2 * pp + 1 < planes;
+    const int n0 = pl0 / p.in_c, c0 = pl0 - n0 * p.in_c, n1 = pl1 / p.in_c, c1 = pl1 - n1 * p.in_c;
+    const T* __restrict__ x0 = (const T*)p.x + (int64_t)n0 * p.in_stride_n + (int64_t)c0 * p.in_stride_c;
+    const T* __restrict__ x1 = (const T*)p.x + (int64_t)n1 * p.in_stride_n + (int64_t)c1 * p.in_stride_c;
+    T* __restrict__ y0 = (T*)p.y + (int64_t)n0 * p.out_stride_n + (int64_t)c0 * p.out_stride_c;
+    T* __restrict__ y1 = (T*)p.y + (int64_t)n1 * p.out_stride_n + (int64_t)c1 * p.out_stride_c;
+    const int ox0 = cb * kColsUp + (lane - sub * lpr) * 16, oy0 = bd * kBand;
+    const int rows = live ? min(kBand, p.out_h - oy0) : 0;
+    const bool col_ok = live && ox0 < p.out_w;
+
+    float f[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float v = 0.f;
+            if (t < p.f_w && i < p.f_h) {
+                const int sx = p.flip ? t : p.f_w - 1 - t, sy = p.flip ? i : p.f_h - 1 - i;
+                v = p.f[(int64_t)sx * p.f_stride_w + (int64_t)sy * p.f_stride_h] * p.gain;
+            }
+            f[i][t] = v;
+        }
+
+    const int e0 = oy0 - p.pad_y0;
+    const int r_first = (e0 >= 0) ? e0 / 2 : -((1 - e0) / 2);      // floor(e0 / 2)
+    const int ix_main = ox0 / 2;                                   // in[e] is input column ix_main - 4 + e
+    auto load_row = [&](int k, Row& row) __attribute__((always_inline)) {
+        const int r = r_first + k;
+        const bool row_ok = r >= 0 && r < p.in_h && col_ok && k < rows / 2 + 3;
+        const bool m_ok = row_ok && ix_main < p.in_w, l_ok = row_ok && ix_main >= 8 && ix_main - 4 < p.in_w,
+                   r_ok = row_ok && ix_main + 8 < p.in_w;
+        const int64_t off = (int64_t)r * p.in_stride_h + ix_main;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const T* src = (q ? x1 : x0) + off;
+            row.m[q] = m_ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+            row.l[q] = l_ok ? *reinterpret_cast<const uint2*>(src - 4) : make_uint2(0, 0);
+            row.r[q] = r_ok ? *reinterpret_cast<const uint2*>(src + 8) : make_uint2(0, 0);
+        }
+    };
+
+    f32x2_t pend[2][16];          // [0]: output row e = 2r - 2 so far (filter row 0 of input row r - 1), [1]: e = 2r - 3 (filter row 1)
+#pragma unroll
+    for (int j = 0; j < 32; j++) pend[j >> 4][j & 15] = f32x2_t{0.f, 0.f};
+
+    auto store_row = [&](int e, const f32x2_t (&v)[16]) __attribute__((always_inline)) {
+        const int oy = e + p.pad_y0;
+        if (oy < oy0 || oy >= oy0 + rows || !col_ok) return;
+        const int64_t off = (int64_t)oy * p.out_stride_h + ox0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            *reinterpret_cast<uint4*>(y0 + off + 8 * h) =
+                make_uint4(Pair<T>::pack(v[8 * h][0], v[8 * h + 1][0]), Pair<T>::pack(v[8 * h + 2][0], v[8 * h + 3][0]),
+                           Pair<T>::pack(v[8 * h + 4][0], v[8 * h + 5][0]), Pair<T>::pack(v[8 * h + 6][0], v[8 * h + 7][0]));
+            if (second)
+                *reinterpret_cast<uint4*>(y1 + off + 8 * h) =
+                    make_uint4(Pair<T>::pack(v[8 * h][1], v[8 * h + 1][1]), Pair<T>::pack(v[8 * h + 2][1], v[8 * h + 3][1]),
+                               Pair<T>::pack(v[8 * h + 4][1], v[8 * h + 5][1]), Pair<T>::pack(v[8 * h + 6][1], v[8 * h + 7][1]));
+        }
+    };
+    auto consume = [&](int k, const Row& row) __attribute__((always_inline)) {
+        f32x2_t in[16];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const unsigned a = j ? row.l[0].y : row.l[0].x, b = j ? row.l[1].y : row.l[1].x;
+            in[2 * j] = f32x2_t{Pair<T>::lo(a), Pair<T>::lo(b)};
+            in[2 * j + 1] = f32x2_t{Pair<T>::hi(a), Pair<T>::hi(b)};
+            const unsigned c = j ? row.r[0].y : row.r[0].x, d = j ? row.r[1].y : row.r[1].x;
+            in[12 + 2 * j] = f32x2_t{Pair<T>::lo(c), Pair<T>::lo(d)};
+            in[12 + 2 * j + 1] = f32x2_t{Pair<T>::hi(c), Pair<T>::hi(d)};
+        }
+        const unsigned ma[4] = {row.m[0].x, row.m[0].y, row.m[0].z, row.m[0].w};
+        const unsigned mb[4] = {row.m[1].x, row.m[1].y, row.m[1].z, row.m[1].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            in[4 + 2 * j] = f32x2_t{Pair<T>::lo(ma[j]), Pair<T>::lo(mb[j])};
+            in[4 + 2 * j + 1] = f32x2_t{Pair<T>::hi(ma[j]), Pair<T>::hi(mb[j])};
+        }
+        // horizontal: output column ox0 + j reads the taps t of its parity, input column ix_main + (j - PADX + t) / 2
+        auto hrow = [&](int i, f32x2_t (&v)[16], bool accumulate) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                f32x2_t a = accumulate ? v[j] : f32x2_t{0.f, 0.f};
+#pragma unroll
+                for (int t = (j + PADX) & 1; t < 4; t += 2) {
+                    const int num = j - PADX + t;                      // even
+                    const int e = 4 + (num >= 0 ? num / 2 : -((-num) / 2));
+                    a = __builtin_elementwise_fma(f32x2_t{f[i][t], f[i][t]}, in[e], a);
+                }
+                v[j] = a;
+            }
+        };
+        const int r = r_first + k;
+        hrow(3, pend[1], true);
+        store_row(2 * r - 3, pend[1]);
+        hrow(2, pend[0], true);
+        store_row(2 * r - 2, pend[0]);
+        hrow(1, pend[1], false);
+        hrow(0, pend[0], false);
+    };
+
+    Row ra, rb;
+    load_row(0, ra);
+    load_row(1, rb);
+    const int total = min(kBand, p.out_h) / 2 + 3;
+    for (int k0 = 0; k0 < total; k0 += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int k = k0 + s;
+            Row cur = s ? rb : ra;
+            load_row(k + 2, s ? rb : ra);
+            consume(k, cur);
+        }
+    }
+}
+
+template <class T, int PADX>
+int launch_up2(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    const int cblocks = (p.out_w + 1023) / 1024, bands = (p.out_h + kBand - 1) / kBand;
+    const int lpr = cblocks > 1 ? 64 : p.out_w / 16;
+    const int64_t pairs = ((int64_t)p.in_n * p.in_c + 1) / 2;
+    const int64_t units = pairs * cblocks * bands;
+    SG_REQUIRE(units <= INT32_MAX / 2, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
+    const int64_t waves = (units + 64 / lpr - 1) / (64 / lpr);
+    hipLaunchKernelGGL((up2_stream_kernel<T, PADX>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p, lpr, cblocks, bands, (int)units);
+    return check_launch("sg_upfirdn2d (up-sampling stream)");
+}
+
+template <class T>
+int launch_up2_pad(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    switch (p.pad_x0) {
+        case 0: return launch_up2<T, 0>(p, stream);
+        case 1: return launch_up2<T, 1>(p, stream);
+        case 2: return launch_up2<T, 2>(p, stream);
+        default: return launch_up2<T, 3>(p, stream);
+    }
+}
+
 // columns [col0, col_end) of every plane: col_end - col0 is a multiple of 8 and, beyond 512, of 512
 template <class T, int PADX>
 int launch_columns(const sg_upfirdn2d_params& p, const sg_epilogue* ep, int col0, int col_end, hipStream_t stream) {
@@ -263,6 +572,36 @@ bool blur_stream_eligible(const sg_upfirdn2d_params& p, const sg_epilogue* ep) {
         if (!(ep->gain > 0.f) || (ep->act == 3 && !(ep->alpha >= 0.f && ep->alpha <= 1.f))) return false;        // gain folded in, lrelu as a max
     }
     return true;
+}
+
+bool down2_stream_eligible(const sg_upfirdn2d_params& p) {
+    if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
+    if (p.up_x != 1 || p.up_y != 1 || p.down_x != 2 || p.down_y != 2 || p.f_w > 4 || p.f_h > 4) return false;
+    if (p.in_stride_w != 1 || p.out_stride_w != 1 || p.pad_x0 < 0 || p.pad_x0 > 3) return false;
+    if (p.in_w % 8 != 0 || p.out_w % 8 != 0 || p.out_w < 32) return false;
+    if (p.in_stride_h % 8 != 0 || p.in_stride_c % 8 != 0 || p.in_stride_n % 8 != 0) return false;
+    if (p.out_stride_h % 8 != 0 || p.out_stride_c % 8 != 0 || p.out_stride_n % 8 != 0) return false;
+    return aligned16(p.x) && aligned16(p.y);
+}
+
+int down2_stream_launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    if (p.dtype == SG_BF16) return launch_down2_pad<__hip_bfloat16>(p, stream);
+    return launch_down2_pad<__half>(p, stream);
+}
+
+bool up2_stream_eligible(const sg_upfirdn2d_params& p) {
+    if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
+    if (p.up_x != 2 || p.up_y != 2 || p.down_x != 1 || p.down_y != 1 || p.f_w > 4 || p.f_h > 4) return false;
+    if (p.in_stride_w != 1 || p.out_stride_w != 1 || p.pad_x0 < 0 || p.pad_x0 > 3) return false;
+    if (p.in_w % 8 != 0 || p.out_w % 16 != 0 || p.out_w < 64 || p.out_h % 2 != 0) return false;
+    if (p.in_stride_h % 8 != 0 || p.in_stride_c % 8 != 0 || p.in_stride_n % 8 != 0) return false;
+    if (p.out_stride_h % 8 != 0 || p.out_stride_c % 8 != 0 || p.out_stride_n % 8 != 0) return false;
+    return aligned16(p.x) && aligned16(p.y);
+}
+
+int up2_stream_launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
+    if (p.dtype == SG_BF16) return launch_up2_pad<__hip_bfloat16>(p, stream);
+    return launch_up2_pad<__half>(p, stream);
 }
 
 int blur_stream_launch(const sg_upfirdn2d_params& p, const sg_epilogue* ep, hipStream_t stream) {

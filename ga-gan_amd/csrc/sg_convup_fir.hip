@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
     int done_idx = 0;
     int buf = 0;
     // `mine` held this step's packets (committed: free again), `other` holds the next step's
-    int nstep = 0;
+    [[maybe_unused]] int nstep = 0;
     auto step = [&](Stage& mine, Stage& other) __attribute__((always_inline)) {
         STAMP(0);
         if (p2.ok) issue(p2, mine);

@@ -12,4 +12,12 @@ namespace sg {
 bool blur_stream_eligible(const sg_upfirdn2d_params& p, const sg_epilogue* ep);
 int blur_stream_launch(const sg_upfirdn2d_params& p, const sg_epilogue* ep, hipStream_t stream);
 
+// up = 1, down = 2 under the same conditions (the filter in front of the discriminator's 1x1 skip convolutions)
+bool down2_stream_eligible(const sg_upfirdn2d_params& p);
+int down2_stream_launch(const sg_upfirdn2d_params& p, hipStream_t stream);
+
+// up = 2, down = 1 under the same conditions, output rows of whole pairs of packets (the adjoint of the above)
+bool up2_stream_eligible(const sg_upfirdn2d_params& p);
+int up2_stream_launch(const sg_upfirdn2d_params& p, hipStream_t stream);
+
 }  // namespace sg

@@ -395,8 +395,14 @@ int launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
     if (rows_contiguous && sizeof(T) <= 4 && p.f_w <= 4 && p.f_h <= 4) {
         const int ux = p.up_x, uy = p.up_y, dx = p.down_x, dy = p.down_y;
         if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return launch_blur4<T>(p, stream);
-        if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return launch_tiled<T, 2, 2, 1, 1, 4, 4, 64, 16>(p, stream);
-        if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return launch_tiled<T, 1, 1, 2, 2, 4, 4, 64, 8>(p, stream);
+        if (ux == 2 && uy == 2 && dx == 1 && dy == 1) {
+            if (up2_stream_eligible(p)) return up2_stream_launch(p, stream);
+            return launch_tiled<T, 2, 2, 1, 1, 4, 4, 64, 16>(p, stream);
+        }
+        if (ux == 1 && uy == 1 && dx == 2 && dy == 2) {
+            if (down2_stream_eligible(p)) return down2_stream_launch(p, stream);
+            return launch_tiled<T, 1, 1, 2, 2, 4, 4, 64, 8>(p, stream);
+        }
     }
     // One-dimensional passes of a separable filter of up to 12 taps at a factor of two (the wavelet low-pass of the
     // augmentation pipeline's geometric resampler, reference augment.py:352 and :370, and their adjoints).

@@ -84,6 +84,19 @@ HOT = [  # (name, x shape, up, down, padding, gain): the four instances on the g
     ('skip_down', [4, 32, 256, 256], 1, 2, [1, 1, 1, 1], 1.0),
     ('odd_sizes', [3, 5, 131, 77], 1, 2, [2, 1, 1, 2], 1.0),
     ('odd_up', [3, 5, 67, 45], 2, 1, [1, 2, 2, 1], 1.0),
+    # rows of whole 16-byte packets on both sides: the streaming kernels (16-bit tensors)
+    ('stream_blur_after_up', [3, 6, 65, 72], 1, 1, [1, -6, 1, 1], 4.0),        # several bands per wave
+    ('stream_blur_wide', [1, 3, 40, 1024], 1, 1, [2, 9, 2, 2], 1.0),           # odd plane count, 129 packets: head + tail launch
+    ('stream_blur_pad0', [2, 4, 33, 64], 1, 1, [0, 3, 0, 3], 1.0),
+    ('stream_blur_pad3', [2, 4, 33, 64], 1, 1, [3, 0, 3, 0], 1.0),
+    ('stream_down', [3, 5, 64, 128], 1, 2, [1, 1, 1, 1], 1.0),
+    ('stream_down_wide', [1, 2, 70, 2064], 1, 2, [1, 1, 2, 0], 1.0),           # 129 packets out, three bands
+    ('stream_down_pad3', [2, 3, 66, 80], 1, 2, [3, -1, 0, 2], 1.0),
+    ('stream_up', [3, 5, 32, 64], 2, 1, [2, 1, 2, 1], 4.0),
+    ('stream_up_wide', [1, 3, 35, 1032], 2, 1, [2, 1, 1, 2], 4.0),              # odd plane count, two column blocks, three bands
+    ('stream_up_pad1', [2, 2, 40, 40], 2, 1, [1, 2, 3, 0], 4.0),
+    ('stream_up_pad03', [2, 2, 33, 48], 2, 1, [0, 3, 0, 1], 1.0),
+    ('stream_up_pad3', [2, 2, 33, 48], 2, 1, [3, 0, 2, 1], 1.0),
 ]
 
 

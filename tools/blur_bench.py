@@ -23,3 +23,13 @@ for (n, c, h, w, pads, dt) in ((32, 32, 1025, 1032, (1, -6, 1, 1), torch.bfloat1
     y = fn(); t = timeit(fn)
     nbytes = (x.numel() + y.numel()) * x.element_size()
     print(f'blur {tuple(x.shape)} -> {tuple(y.shape)} {str(dt)[6:]:9s} {t:7.3f} ms  {nbytes / t / 1e6:7.1f} GB/s', flush=True)
+for (n, c, h, w, dt) in ((16, 32, 1024, 1024, torch.bfloat16), (32, 64, 512, 512, torch.bfloat16), (64, 64, 256, 256, torch.bfloat16)):
+    x = torch.randn(n, c, h, w, device='cuda').to(dt)
+    fn = lambda: up.upfirdn2d(x, f, 1, 1, 2, 2, 1, 1, 1, 1, False, 1.0)
+    y = fn(); t = timeit(fn)
+    nbytes = (x.numel() + y.numel()) * x.element_size()
+    print(f'down {tuple(x.shape)} -> {tuple(y.shape)} {str(dt)[6:]:9s} {t:7.3f} ms  {nbytes / t / 1e6:7.1f} GB/s', flush=True)
+    fn = lambda: up.upfirdn2d(y, f, 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0)
+    z = fn(); t = timeit(fn)
+    nbytes = (z.numel() + y.numel()) * x.element_size()
+    print(f'up   {tuple(y.shape)} -> {tuple(z.shape)} {str(dt)[6:]:9s} {t:7.3f} ms  {nbytes / t / 1e6:7.1f} GB/s', flush=True)
