@@ -98,7 +98,7 @@ struct UpFirArgs {
 
 constexpr int kThreads = 512;
 constexpr int kWBytes = kCombos * BCO * kRow;                      // 36864: the weights of one chunk
-constexpr int SLOTS = kThreads / 16, STEPS = (ITEMS + SLOTS - 1) / SLOTS;        // staging: item slots, items per lane
+constexpr int STEPS = 2;                                           // loads of a step per lane and channel: 15 wave-slots of 64 for 8 waves
 constexpr int WPACKETS = kCombos * BCO * 4, WROUNDS = (WPACKETS + kThreads - 1) / kThreads;   // 16-byte weight packets of a chunk
 constexpr int kNoise = 2 * TH * 2 * TW;                            // floats of a tile's noise
 constexpr size_t kLds = 2 * kInBytes + 2 * kWBytes + 3 * kNoise * sizeof(float);   // 147456
@@ -164,10 +164,21 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
         return q;
     };
 
-    const int cg = tid & 15, slot0 = tid >> 4;
     const int ch = 16 * ct + lrow;                 // this lane's output channel inside the group
 
     // ---- loads of a step into registers ------------------------------------------------------------------------------
+    // A wave-slot ws = wave + 8 q (q = 0, 1) is one group of 64 loads: ws < 12 the 4 packets v = 4 (ws & 1) + (lane & 3)
+    // of footprint row ws >> 1 (columns b0 + 8 v ..) for the 16 channel pairs lane >> 2 - four neighbouring lanes read
+    // one 64-byte run; ws = 12 .. 14 the halo packets (columns b0 - 8 .. and b0 + 64 ..) of which only the pixel next
+    // to the tile is kept: item 4 (ws - 12) + (lane & 3) = 2 row + side.
+    const int cg = lane >> 2, v_lo = lane & 3;
+    auto slot_geometry = [&](int q, int& ry, int& col, bool& halo, bool& live) __attribute__((always_inline)) {
+        const int ws = wave + 8 * q;
+        halo = ws >= 12;
+        live = ws < 15;
+        if (!halo) { ry = ws >> 1; col = 8 + 8 * (4 * (ws & 1) + v_lo); }       // column inside the staged row (LWP pixels)
+        else { const int item = 4 * (ws - 12) + v_lo; ry = item >> 1; col = (item & 1) ? 8 + TW : 0; }
+    };
     auto issue = [&](const Pos& p, Stage& st) __attribute__((always_inline)) {
         const Tile& t = p.t;
         const int c = p.c * KCH + 2 * cg;
@@ -175,22 +186,22 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
         const T* src0 = (const T*)g.x + ((int64_t)t.n * g.ci + c) * plane;
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
-            const int item = slot0 + SLOTS * q;
-            const int ry = item / NV, v = item - ry * NV;
-            const int iy = t.a0 - 1 + ry, px0 = t.b0 - 8 + v * 8;
+            int ry, col; bool halo, live;
+            slot_geometry(q, ry, col, halo, live);
+            const int iy = t.a0 - 1 + ry, px0 = t.b0 - 8 + col;
             st.va[q] = make_uint4(0, 0, 0, 0);
             st.vb[q] = make_uint4(0, 0, 0, 0);
 #ifdef BAND_ABL_NOLOAD
-            st.va[q] = make_uint4(item, q, tid, 1);
+            st.va[q] = make_uint4(ry, q, tid, 1);
             continue;
 #endif
-            if (c_ok && item < ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
+            if (c_ok && live && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
                 const T* src = src0 + iy * g.wid + px0;
                 st.va[q] = *reinterpret_cast<const uint4*>(src);
                 if (two) st.vb[q] = *reinterpret_cast<const uint4*>(src + plane);
             }
         }
-        if (g.in_scale) {
+        if (!RESIDENT && g.in_scale) {
             st.s0 = c_ok ? g.in_scale[(int64_t)t.n * g.ci + c] : 0.f;
             st.s1 = two ? g.in_scale[(int64_t)t.n * g.ci + c + 1] : 0.f;
         }
@@ -206,14 +217,32 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
         }
     };
     uint4 vw[RESIDENT ? 1 : WROUNDS];
-    auto load_weights = [&](int m0, int c0, uint4 (&v)[WROUNDS]) __attribute__((always_inline)) {   // cache-resident: every workgroup reads them
+    // `n` >= 0: the weights are multiplied by that sample's modulation (the resident form: pixels are then staged as
+    // they are)
+    auto load_weights = [&](int m0, int c0, int n, uint4 (&v)[WROUNDS]) __attribute__((always_inline)) {   // cache-resident: every workgroup reads them
+        const int cw = c0 + (tid & 3) * 8;         // (kThreads is a multiple of 4: a lane's packets share their channels)
+        float sc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) sc[j] = 1.f;
+        const bool scaled = RESIDENT && n >= 0 && g.in_scale;
+        if (scaled && cw < g.ci) {
+            const float4 a = *reinterpret_cast<const float4*>(g.in_scale + (int64_t)n * g.ci + cw);
+            const float4 b = *reinterpret_cast<const float4*>(g.in_scale + (int64_t)n * g.ci + cw + 4);
+            sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+        }
 #pragma unroll
         for (int q = 0; q < WROUNDS; q++) {
             const int id = tid + kThreads * q;
-            const int slot = id & 3, o = m0 + ((id >> 2) % BCO), combo = (id >> 2) / BCO;
-            const int cw = c0 + slot * 8;
-            v[q] = make_uint4(0, 0, 0, 0);
-            if (id < WPACKETS && o < g.co && cw < g.ci) v[q] = *reinterpret_cast<const uint4*>(w + ((int64_t)combo * g.co + o) * g.ci + cw);
+            const int o = m0 + ((id >> 2) % BCO), combo = (id >> 2) / BCO;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (id < WPACKETS && o < g.co && cw < g.ci) u = *reinterpret_cast<const uint4*>(w + ((int64_t)combo * g.co + o) * g.ci + cw);
+            if (scaled) {
+                u.x = Pair<T>::pack(Pair<T>::lo(u.x) * sc[0], Pair<T>::hi(u.x) * sc[1]);
+                u.y = Pair<T>::pack(Pair<T>::lo(u.y) * sc[2], Pair<T>::hi(u.y) * sc[3]);
+                u.z = Pair<T>::pack(Pair<T>::lo(u.z) * sc[4], Pair<T>::hi(u.z) * sc[5]);
+                u.w = Pair<T>::pack(Pair<T>::lo(u.w) * sc[6], Pair<T>::hi(u.w) * sc[7]);
+            }
+            v[q] = u;
         }
     };
     auto store_weights = [&](int wbuf, const uint4 (&v)[WROUNDS]) __attribute__((always_inline)) {
@@ -229,25 +258,31 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
     float nscg = 1.f, nbsg = 0.f;      // epilogue constants of the tile whose first chunk was committed last
     auto commit = [&](const Pos& p, const Stage& st, int buf) __attribute__((always_inline)) {
         unsigned char* img = s_in + buf * kInBytes;
+        const bool scale = !RESIDENT && g.in_scale;
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
-            const int item = slot0 + SLOTS * q;
-            if (item >= ITEMS) continue;
+            int ry, col; bool halo, live;
+            slot_geometry(q, ry, col, halo, live);
+            if (!live) continue;
             const unsigned wa[4] = {st.va[q].x, st.va[q].y, st.va[q].z, st.va[q].w};
             const unsigned wb[4] = {st.vb[q].x, st.vb[q].y, st.vb[q].z, st.vb[q].w};
-            const int r0 = item * 8;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
+            const int r0 = ry * LWP + col;
+            auto put = [&](int j) __attribute__((always_inline)) {
                 const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
                 unsigned out;
-                if (g.in_scale) out = Pair<T>::pack(Pair<T>::lo(ea) * st.s0, Pair<T>::lo(eb) * st.s1);
+                if (scale) out = Pair<T>::pack(Pair<T>::lo(ea) * st.s0, Pair<T>::lo(eb) * st.s1);
                 else out = (ea & 0xffffu) | (eb << 16);
 #ifdef BAND_ABL_NOCOMMIT
                 asm volatile("" :: "v"(out));
 #else
                 *reinterpret_cast<unsigned*>(img + swz(r0 + j, cg * 4)) = out;
 #endif
-            }
+            };
+            if (!halo) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) put(j);
+            } else if (col == 0) put(7);       // column b0 - 1
+            else put(0);                       // column b0 + 64
         }
         if (p.c == 0) {
             if (g.noise && tid < kNoise / 4) *reinterpret_cast<float4*>(s_noise + (p.idx % 3) * kNoise + 4 * tid) = st.vn;
@@ -362,14 +397,20 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
     sa.vn = sb.vn = make_float4(0.f, 0.f, 0.f, 0.f);
     sa.s0 = sa.s1 = sb.s0 = sb.s1 = 1.f;
     issue(p0, sa);
-    {
+    auto stage_resident = [&](const Tile& t) __attribute__((always_inline)) {   // the whole composed kernel, modulated for t's sample
         uint4 v[WROUNDS];
-        load_weights(p0.t.m0, 0, v);
+        load_weights(t.m0, 0, t.n, v);
         store_weights(0, v);
-        if (RESIDENT && chunks == 2) {
-            load_weights(p0.t.m0, KCH, v);
+        if (chunks == 2) {
+            load_weights(t.m0, KCH, t.n, v);
             store_weights(1, v);
         }
+    };
+    if constexpr (RESIDENT) stage_resident(p0.t);
+    else {
+        uint4 v[WROUNDS];
+        load_weights(p0.t.m0, 0, -1, v);
+        store_weights(0, v);
     }
     if (p1.ok) issue(p1, sb);
     commit(p0, sa, 0);
@@ -387,7 +428,7 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
         STAMP(0);
         if (p2.ok) issue(p2, mine);
         if constexpr (!RESIDENT) {
-            if (p1.ok) load_weights(p1.t.m0, p1.c * KCH, vw);
+            if (p1.ok) load_weights(p1.t.m0, p1.c * KCH, -1, vw);
         }
         // late waves: the previous tile's filter / epilogue / stores first, then multiply; early waves: multiply, then
         // (after a tile's last chunk) filter / epilogue / stores
@@ -408,6 +449,12 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
         }
         STAMP(5);
         __syncthreads();
+        if constexpr (RESIDENT) {
+            if (g.in_scale && p1.ok && p1.c == 0 && p1.t.n != p0.t.n) {   // (uniform) the next tile is another sample's
+                stage_resident(p1.t);
+                __syncthreads();
+            }
+        }
         STAMP(6);
         nstep++;
         buf ^= 1;

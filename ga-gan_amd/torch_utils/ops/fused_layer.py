@@ -64,8 +64,8 @@ def _filter_taps(f):
 def _one_pass_up(x, w, f, k, blur_pad, extra, act, alpha, gain):
     """(composed weights, vertical taps) when the one-pass kernel covers this up-sampling layer, else None."""
     # Beyond 128 input channels the layer is bound by its matrix work, which the one-pass form doubles (18 tap
-    # combinations instead of 9): there the two passes are faster (256 -> 128 channels at 128^2, 32 samples: 1.08 ms
-    # against 1.20 ms; 128 -> 64 at 256^2: 1.58 against 1.36; 64 -> 32 at 512^2: 2.88 against 1.54).
+    # combinations instead of 9): there the two passes are faster (256 -> 128 channels at 128^2, 32 samples: 0.96 ms
+    # against 1.11 ms; 128 -> 64 at 256^2: 1.32 against 1.27; 64 -> 32 at 512^2: 2.36 against 1.46).
     if x.shape[1] > ONE_PASS_UP_MAX_CHANNELS:
         return None
     if k != 3 or tuple(blur_pad) != (1, 1 - extra, 1, 1) or not _layer.conv_up2_fir_supported(x, w.shape[0], act, alpha, gain):
