@@ -32,9 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak
-# dense matrix-core peaks.  float32 convolutions run on the bf16 instruction, six partial products per float product
-# (exact three-way split of both operands): their ceiling in float-equivalent flops is a sixth of the bf16 peak.
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'float': 2500.0 / 6}
+# dense matrix-core peaks.  float32 convolutions run on the 16-bit matrix instruction, three partial products per float
+# product (both operands cut into two half-precision pieces, the low x low product dropped): their ceiling in
+# float-equivalent flops is a third of the 16-bit peak.
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'float': 2500.0 / 3}
 
 CONFIGS = {
     # name: (description, cfg preset, resolution, per-GPU batch, parameterisation)
@@ -79,18 +80,18 @@ def make_trainer(args, rank, world, config=None):
             desc + (' + ADA (bgc)' if extra else ''), res, batch_gpu)
 
 
-def traffic_file():
-    """The newest committed counter summary (profiles/rN_traffic.json), or None."""
-    names = sorted(n for n in os.listdir(os.path.join(ROOT, 'profiles')) if n.endswith('_traffic.json')) \
+def traffic_file(config):
+    """The newest committed counter summary of the workload (profiles/rN_traffic_<config>.json), or None."""
+    names = sorted(n for n in os.listdir(os.path.join(ROOT, 'profiles')) if n.endswith('_traffic_%s.json' % config)) \
         if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
     return os.path.join(ROOT, 'profiles', names[-1]) if names else None
 
 
-def measured_traffic(label):
+def measured_traffic(label, config):
     """HBM-side bytes per launch of the kernel `label` (symbol<dtype>) from the committed counter runs of this same
-    command (profiles/r1_traffic.json, written by tools/summarize_traffic.py from rocprofv3 FETCH_SIZE / WRITE_SIZE
-    passes); None when the file has no entry.  All template instances of the symbol and dtype are pooled."""
-    path = traffic_file()
+    workload (profiles/rN_traffic_<config>.json, written by tools/summarize_traffic.py from rocprofv3 FETCH_SIZE /
+    WRITE_SIZE passes); None when the file has no entry.  All template instances of the symbol and dtype are pooled."""
+    path = traffic_file(config)
     if path is None:
         return None
     symbol, _, dtype = label.partition('<')
@@ -103,15 +104,15 @@ def measured_traffic(label):
     return int(total / launches) if launches else None
 
 
-def traffic_source(label):
+def traffic_source(label, config):
     """Where `roofline.traffic` comes from: it is not measured in this run (counters need rocprofv3 passes of their own)."""
-    path = traffic_file()
-    if path is None or measured_traffic(label) is None:
+    path = traffic_file(config)
+    if path is None or measured_traffic(label, config) is None:
         return None
-    return 'profiles/%s: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, per launch' % os.path.basename(path)
+    return 'profiles/%s: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload, per launch' % os.path.basename(path)
 
 
-def kernel_roofline(trainer, real, real_c, steps):
+def kernel_roofline(trainer, real, real_c, steps, config):
     """Instrumented pass: HIP events around every launch of the hand-written kernels (recorded on the
     stream they are launched on), grouped by kernel symbol.  The kernel with the largest total time is the
     dominant one: for the matrix-core convolutions it is priced against the dense MFMA peak of its dtype
@@ -139,13 +140,13 @@ def kernel_roofline(trainer, real, real_c, steps):
         peak = MFMA_PEAK_TFLOPS['float' if '<float' in name else 'bf16']
         achieved = (k['flops'] / k['launches']) / (avg_ms * 1e-3) / 1e12
         roofline = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 4), traffic=measured_traffic(name), traffic_source=traffic_source(name), launches=k['launches'],
+                        frac=round(achieved / peak, 4), traffic=measured_traffic(name, config), traffic_source=traffic_source(name, config), launches=k['launches'],
                         avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_flops_per_launch=int(k['flops'] / k['launches']),
                         algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
     else:
         achieved = (k['bytes'] / k['launches']) / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(name), traffic_source=traffic_source(name), launches=k['launches'],
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(name, config), traffic_source=traffic_source(name, config), launches=k['launches'],
                         avg_launch_us=round(avg_ms * 1e3, 2), algorithmic_bytes_per_launch=int(k['bytes'] / k['launches']))
     summary = {n: dict(launches_per_step=v['launches'] // steps, ms_per_step=round(v['ms'] / steps, 3),
                        gbps=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1),
@@ -277,7 +278,7 @@ def run_workload(args, config, steps, warmup, rank, world, local_rank, note, wit
     note(f'timed region: {elapsed:.3f}s')
     roofline, kernels = (None, {})
     if with_roofline:
-        roofline, kernels = kernel_roofline(trainer, real, real_c, min(steps, 4))
+        roofline, kernels = kernel_roofline(trainer, real, real_c, min(steps, 4), config)
         barrier()
     global_batch = batch_gpu * world
     out = dict(value=round(steps * global_batch / elapsed, 3), unit='img/s', steps=steps, warmup=warmup,

@@ -17,8 +17,8 @@ def fold(directory, counter):
         for row in csv.DictReader(open(path)):
             if row['Counter_Name'] != counter or 'sg::' not in row['Kernel_Name']:
                 continue
-            name = re.sub(r'^void sg::\(anonymous namespace\)::', '', row['Kernel_Name'])
-            name = re.sub(r'\(.*$', '', name)
+            name = re.sub(r'\(anonymous namespace\)::', '', re.sub(r'^void ', '', row['Kernel_Name']))
+            name = re.sub(r'^sg::', '', re.sub(r'\(.*$', '', name))
             entry = per[name]
             entry[0] += float(row['Counter_Value']) * 1024.0
             entry[1] += 1
@@ -35,7 +35,7 @@ def main():
                             fetch_bytes_per_launch=round(2.0 * f[0] / max(f[1], 1)),
                             write_bytes_per_launch=round(w[0] / max(w[1], 1)))
     json.dump(dict(note='HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2, gfx950 correction for wide reads) and '
-                        'WRITE_SIZE, separate passes of bench.py --steps 4 --warmup 1', kernels=result), open(out, 'w'), indent=1)
+                        'WRITE_SIZE, separate passes of bench.py --config <workload> --steps 4 --warmup 1 --also none (tools/prof_bench.sh)', kernels=result), open(out, 'w'), indent=1)
     for name, v in sorted(result.items(), key=lambda kv: -kv[1]['launches'] * (kv[1]['fetch_bytes_per_launch'] + kv[1]['write_bytes_per_launch'])):
         print(f"{v['launches']:6d}  {v['fetch_bytes_per_launch'] / 1e6:9.1f} MB read  {v['write_bytes_per_launch'] / 1e6:9.1f} MB written  {name}")
 
