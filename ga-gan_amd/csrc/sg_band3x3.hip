@@ -5,8 +5,11 @@
 //
 //   * A persistent workgroup of 8 waves owns a BAND of 6 output rows of one sample and 32 output channels, and walks
 //     it from left to right in steps of 64 pixels.  The 9 right-most input columns of a step stay in LDS for the next
-//     one, so each step loads exactly the 64 new columns, never a halo column.  Outputs lag the loads by 8 columns
-//     (step t produces columns 64 t - 8 .. 64 t + 55), which keeps the stores 16-byte aligned.
+//     one, so each step loads exactly the 64 new columns, never a halo column.  The LOADS run 8 columns ahead of the
+//     outputs (step t loads input columns 64 t - 56 .. 64 t + 7 and produces output columns 64 t - 64 .. 64 t - 1;
+//     step 0 only loads): the stores then cover whole 128-byte lines within one step, and the misalignment sits on
+//     the loads, where the second touch of a line is a cache hit (with the outputs lagging instead, every line left
+//     the L2 as three partial requests: 1.5 x the bytes on the memory side).
 //   * The weights of the workgroup's channels (with the per-sample modulation folded in: w * s[n, ci]) live in
 //     REGISTERS as matrix-instruction fragments for the whole band (72 registers): the multiply phase reads nothing
 //     but pixels from LDS, one 16-byte read per 1.5 matrix instructions.
@@ -62,7 +65,7 @@ constexpr int R = 6;                     // output rows of a band
 constexpr int IH = R + 2;                // image rows: row r holds input row y0 - 1 + r
 constexpr int TWX = 64;                  // new input columns per step
 constexpr int CARRY = 9;                 // columns kept from the previous step
-constexpr int IW = TWX + CARRY;          // image columns: column i holds input column 64 t - 9 + i (odd: see img_off)
+constexpr int IW = TWX + CARRY;          // image columns: column i of step t holds input column 64 t - 65 + i (odd: see img_off)
 constexpr int kPix = 64;                 // bytes per pixel: 32 channels
 constexpr int kImg = IH * IW * kPix;     // 37376 bytes per image
 constexpr int kNoise = R * TWX;          // floats of a step's noise tile
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
     const int pi = 16 * ((lc >> 2) & 1) + 4 * (lc >> 3) + (lc & 3);
     const int c0px = 32 * sx + pi;                    // image column of this lane's pixel for the left tap
 
-    const int NT = (g.wid + TWX - 1) / TWX;           // loading steps; step NT only finishes the last 8 columns
+    const int NT = (g.wid + TWX - 1) / TWX;           // output steps 1 .. NT; step 0 only loads (columns 0 .. 7)
     const int Q = NT + 1;
     const int64_t plane = (int64_t)g.h * g.wid;
     const unsigned uplane = (unsigned)plane;
@@ -220,8 +223,8 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
 
         // ---- staging: loads of a step into registers, later masked / transposed / written to LDS -------------------
         auto issue = [&](int q, Staged<MASK>& st) {
-            const int col = q * TWX + 8 * u_v, yy = y0 - 1 + u_r;
-            const bool ok = q < NT && col < g.wid && yy >= 0 && yy < g.h;
+            const int col = (q - 1) * TWX + 8 + 8 * u_v, yy = y0 - 1 + u_r;
+            const bool ok = col >= 0 && col < g.wid && yy >= 0 && yy < g.h;
             const unsigned off = ok ? ((unsigned)(4 * u_c4) * uplane + (unsigned)(yy * g.wid + col)) * 2u : kOutside;   // bytes
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -232,9 +235,9 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
                 st.p[e] = load16(xr, off, e * uplane * 2u);
                 if constexpr (MASK) st.m[e] = load16(mr, off, e * uplane * 2u);
             }
-            // noise tile of the step (output columns 64 q - 8 ..): lanes 384..511, one float4 each
+            // noise tile of the step (output columns 64 (q - 1) ..): lanes 384..511, one float4 each
             if (g.noise && tid >= 384) {
-                const int id = tid - 384, row = y0 + (id >> 4), c = q * TWX - 8 + 4 * (id & 15);
+                const int id = tid - 384, row = y0 + (id >> 4), c = (q - 1) * TWX + 4 * (id & 15);
                 st.pn = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((id >> 4) < R && row < g.h && c >= 0 && c < g.wid)
                     st.pn = *reinterpret_cast<const float4*>(g.noise + (int64_t)n * g.noise_stride + (int64_t)row * g.wid + c);
@@ -282,14 +285,14 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
         f32x16_t acc[2];
         uint4 rx[REDUCE ? 2 : 1][2];
         float red = 0.f;
-        auto active = [&](int t) { return (t < NT || sx == 0) && rg < 3; };   // the closing step only has the 8 left-most columns left
+        auto active = [&](int t) { return t >= 1 && rg < 3; };   // the opening step only loads
         auto load_rx = [&](int t) {
             if constexpr (REDUCE) {
 #pragma unroll
                 for (int o = 0; o < 2; o++)
 #pragma unroll
                     for (int gq = 0; gq < 2; gq++) {
-                        const int row = y0 + 2 * rg + o, col0 = t * TWX - 8 + 32 * sx + 16 * hh + 8 * gq;
+                        const int row = y0 + 2 * rg + o, col0 = (t - 1) * TWX + 32 * sx + 16 * hh + 8 * gq;
                         const bool ok = row < g.h && col0 >= 0 && col0 < g.wid;
                         rx[o][gq] = load16(rr, ok ? ((unsigned)cout * uplane + (unsigned)(row * g.wid + col0)) * 2u : kOutside, 0);
                     }
@@ -369,7 +372,7 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
             for (int k = 0; k < 4; k++) {
                 const int run = 16 * k + (lane >> 2), piece = lane & 3, o = k >> 1, ch = run & 31;
                 const uint4 out = *reinterpret_cast<const uint4*>(s_out + run * kOutRow + 16 * piece);
-                const int row = y0 + 2 * rg + o, col = t * TWX - 8 + 32 * sx + 8 * piece;
+                const int row = y0 + 2 * rg + o, col = (t - 1) * TWX + 32 * sx + 8 * piece;
                 const bool ok = row < g.h && col >= 0 && col < g.wid;
 #ifdef BAND_ABL_NOSTORE
                 asm volatile("" :: "v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
