@@ -31,12 +31,16 @@
 // stay at the 1e-6 relative error of a float32 evaluation).  Three 16x16x32 instructions take 48 cycles per 32
 // channels where eight 16x16x4 float ones take 256.  A chunk is 32 channels (2 x 64 bytes per pixel row, pitch
 // 144); the weight chunk is staged three taps at a time so that the tile fits LDS.
+// Layers with enough pixels to give every CU a workgroup of 512 pixels run with such tiles (each of the eight waves
+// then owns 64 channels x 64 pixels): a staged weight feeds twice the multiplies, which halves the weight bytes
+// that the workgroups pull through L2 - the larger share of what they read.
 #include "sg_absmax.h"
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 namespace sg {
 namespace {
@@ -48,6 +52,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kPitch = 80;        // bytes per LDS pixel row: 64 payload + 16 pad
 constexpr int kChunkBytes = 64;   // K payload per pixel per chunk
 constexpr int kPixels = 256;      // output pixels per workgroup
+constexpr int kPixelsWide = 512;  // ... of the float kernel on layers with enough pixels to fill the chip with such tiles
 constexpr int kThreads = 256;
 constexpr int kPitchSplit = 144;  // bytes per LDS pixel row of a float tensor split into 2 half planes: 2 x 64 + 16 pad
 constexpr int kSplitTaps = 3;     // taps of the weight chunk held in LDS at a time (split float path)
@@ -82,7 +87,8 @@ __device__ __forceinline__ void mma_split(const uint4 (&a)[2], const uint4 (&b)[
 
 struct Tile {
     int split_k;          // > 1: input-channel chunks are divided over blockIdx.z, partial sums added atomically
-    int tw, th, imgs;     // pixel tile in phase coordinates; tw * th * imgs <= 256 (slots beyond it are idle)
+    int px;               // pixel slots per workgroup: 256, or 512 (float kernel, large layers)
+    int tw, th, imgs;     // pixel tile in phase coordinates; tw * th * imgs <= px (slots beyond it are idle)
     int lw, lh;           // LDS footprint of one image's tile (pixels)
     int tiles_a, tiles_b, tiles_img;
     int vec_epi;          // epilogue through LDS with 16-byte global accesses (8 pixels of one channel per lane)
@@ -251,12 +257,12 @@ __device__ __forceinline__ void stage_tile(unsigned char* s_dst, const T* __rest
 // staging arithmetic then overlaps the other's multiplies.
 template <class T> constexpr int conv_threads() { return sizeof(T) == 4 ? 512 : 256; }
 
-template <class T, int M_TILES>
+template <class T, int M_TILES, int PX = kPixels>
 __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) conv2d_mfma_kernel(sg_conv2d_params p, Tile t) {
     using S = float;
     constexpr bool SPLIT = sizeof(T) == 4;              // float: two half planes per operand
     constexpr int THREADS = conv_threads<T>(), WAVES = THREADS / 64;
-    constexpr int NT = kPixels / (16 * WAVES);          // 16-pixel n-tiles per wave: 4 or 2
+    constexpr int NT = PX / (16 * WAVES);               // 16-pixel n-tiles per wave: 4 or 2 (4 with 512 pixels)
     constexpr int WPX = 16 * NT;                        // pixel slots per wave
     constexpr int KCH = SPLIT ? 32 : kChunkBytes / (int)sizeof(T);   // channels per chunk
     constexpr int PITCH = SPLIT ? kPitchSplit : kPitch;
@@ -348,7 +354,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         // input footprint when a new chunk begins - are issued into registers before the multiplies of the current
         // one and written to LDS after them.
         constexpr int W_IT = (kSplitTaps * BM * 8 + THREADS - 1) / THREADS;   // 16-byte pieces per lane
-        constexpr int X_IT = 8;                                               // input pieces per lane held in registers
+        constexpr int X_IT = PX == kPixels ? 8 : 10;                          // input pieces per lane held in registers
         const unsigned char* __restrict__ xs = t.xs;
         const unsigned char* __restrict__ ws = t.ws + (ph.w_offset / p.ci) * (int64_t)128;   // (this phase's first row)
         const int x_items = t.imgs * lh * lw * 8;
@@ -378,7 +384,9 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         };
         // Where piece e of the footprint lies in the split tensor, in 16-byte units for chunk 0 (-1: outside the
         // tensor, zero).  The same for every chunk, so the divisions are done once per lane.
-        auto x_where = [&](int e) -> int64_t {
+        // (the wide tile keeps the offsets in 32 bits - the host picks it for tensors below 2^31 such units only)
+        using XOff = typename std::conditional<PX == kPixels, int64_t, int>::type;
+        auto x_where = [&](int e) -> XOff {
             const int piece = e & 7;
             int pix = e >> 3;
             const int rx = pix % lw; pix /= lw;
@@ -386,12 +394,12 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             const int ri = pix / lh;
             const int iy = iy0 + ry, ix = ix0 + rx, n = img0 + ri;
             if (e >= x_items || iy < 0 || iy >= p.h || ix < 0 || ix >= p.w_in || n >= p.n) return -1;
-            return (((int64_t)n * chunks * p.h + iy) * p.w_in + ix) * 8 + piece;
+            return (XOff)((((int64_t)n * chunks * p.h + iy) * p.w_in + ix) * 8 + piece);
         };
-        int64_t xoff[X_IT];
+        XOff xoff[X_IT];
 #pragma unroll
         for (int k = 0; k < X_IT; k++) xoff[k] = x_where(tid + k * THREADS);
-        auto x_fetch = [&](int cb, int64_t where) -> uint4 {   // (no branch: a piece outside is read at the tensor's start and dropped)
+        auto x_fetch = [&](int cb, XOff where) -> uint4 {   // (no branch: a piece outside is read at the tensor's start and dropped)
             const uint4 v = *reinterpret_cast<const uint4*>(xs + (where < 0 ? 0 : (where + (int64_t)cb * x_plane8) * 16));
             return where < 0 ? make_uint4(0, 0, 0, 0) : v;
         };
@@ -723,7 +731,7 @@ int ilog2(int v) {
 // pixel slots in all.  Extents below 32 that are no power of two get a tile of exactly their size (a 9 x 12 phase
 // of an up-sampling layer would fill 42% of a 16 x 16 tile), except where the per-image reduction is wanted,
 // whose shuffle groups need tiles of whole 16-pixel groups.
-Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
+Tile make_tile_of(const sg_conv2d_params& p, int px, int* out_max_taps) {
     const bool split = p.dtype == SG_F32;   // LDS rows and weight-chunk rows of the kernel that runs this dtype
     const size_t pitch = split ? kPitchSplit : kPitch;
     int AH = 0, AW = 0, max_taps = 0, max_nky = 0, max_nkx = 0;
@@ -739,15 +747,20 @@ Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     Tile t;
     t.split_k = 1;
     t.vec_epi = 0;
+    t.px = px;
     t.tw = 32;
     while (t.tw > 1 && t.tw / 2 >= AW) t.tw /= 2;              // smallest power of two covering AW, at most 32
     if (exact && AW < t.tw) t.tw = AW;
-    int rest = kPixels / t.tw;
-    t.th = (p.in_step == 1) ? 8 : 4;
+    // Polyphase layers have extents like 33 (the even phase of 32 -> 65): tiles of equal width instead of 32 + 1
+    const bool balance = exact && p.num_phases > 1;
+    if (balance && AW > t.tw) t.tw = (AW + (AW + t.tw - 1) / t.tw - 1) / ((AW + t.tw - 1) / t.tw);
+    int rest = px / t.tw;
+    t.th = (p.in_step == 1) ? px / 32 : 4;
     if (exact && t.tw < 32) t.th = 16;                          // low resolution: whole images where they fit
     if (t.th > rest) t.th = rest;
     if (exact && AH < t.th) t.th = AH;
     while (!exact && t.th > 1 && t.th / 2 >= AH) t.th /= 2;
+    if (balance && AH > t.th) t.th = (AH + (AH + t.th - 1) / t.th - 1) / ((AH + t.th - 1) / t.th);
     t.lw = (t.tw - 1) * p.in_step + max_nkx;
     if (split) {
         // Rows of 144 bytes: pick the rows x images per tile that fill the most pixel slots within the LDS budget
@@ -780,6 +793,18 @@ Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
     return t;
 }
 
+// The float kernel takes 512 pixels per workgroup (every staged weight then feeds twice the multiplies, and the
+// weights are what its workgroups read most of) where such tiles are filled and still give every CU a workgroup.
+Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
+    if (p.dtype == SG_F32 && p.co >= 64) {
+        const Tile t = make_tile_of(p, kPixelsWide, out_max_taps);
+        const bool small = split_bytes((int64_t)p.n * p.h * p.w_in, p.ci) / 16 < (size_t)INT32_MAX;
+        const int64_t blocks = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img * p.num_phases * ((p.co + 63) / 64);
+        if (small && t.imgs * t.th * t.tw >= kPixelsWide * 3 / 4 && blocks >= 256) return t;
+    }
+    return make_tile_of(p, kPixels, out_max_taps);
+}
+
 template <class T>
 int launch(const sg_conv2d_params& p, hipStream_t stream) {
     int max_taps = 0;
@@ -800,7 +825,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     // 64 output channels per workgroup (every staged pixel then feeds four times the multiplies), unless that
     // leaves most of the 256 CUs without a workgroup even with the channel sum divided
     const int64_t tiles_px = tiles * p.num_phases;
-    const int m_tiles = (p.co > 16 && tiles_px * ((p.co + 63) / 64) * max_split >= 256) ? 4 : 1;
+    const int m_tiles = (t.px > kPixels || (p.co > 16 && tiles_px * ((p.co + 63) / 64) * max_split >= 256)) ? 4 : 1;
     const int BM = 16 * m_tiles;
     size_t lds = ((size_t)t.imgs * t.lh * t.lw + (size_t)max_taps * BM) * PITCH;
     t.max_taps = max_taps;
@@ -828,7 +853,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     t.vec_epi = t.split_k == 1 && p.out_step == 1 && p.num_phases == 1 && p.phase[0].oy0 == 0 && p.phase[0].ox0 == 0 &&
                 p.ow % 8 == 0 && t.tw % 8 == 0 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
                 (!p.reduce_out || aligned16(p.reduce_x));
-    if (t.vec_epi) lds = std::max(lds, (size_t)kPixels * (BM + 4) * sizeof(float));
+    if (t.vec_epi) lds = std::max(lds, (size_t)t.px * (BM + 4) * sizeof(float));
     t.amax = nullptr;
     t.xs = t.ws = nullptr;
     t.chunks = 0;
@@ -859,6 +884,9 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     }
     dim3 grid((unsigned)tiles, (unsigned)((p.co + BM - 1) / BM), (unsigned)(p.num_phases * t.split_k));
     auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
+    if constexpr (SPLIT) {
+        if (t.px > kPixels) kernel = conv2d_mfma_kernel<T, 4, kPixelsWide>;
+    }
     if (lds > 64 * 1024) {   // opt in to large dynamic LDS (idempotent, cheap)
         hipError_t e = allow_large_lds((const void*)kernel);
         if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));

@@ -108,6 +108,51 @@ def test_conv2d_fused_layer(dtype, up):
         close(y, want, 2 * ULP[dtype], f'up{up} noise{tuple(noise.shape)}')
 
 
+WIDE_CASES = [  # name, n, ci, co, h, w, kind: float32 layers large enough for the 512-pixel tile of the float kernel
+    ('f32_wide', 8, 48, 256, 64, 64, 'conv'),
+    ('f32_wide_ragged', 6, 40, 264, 50, 72, 'conv'),
+    ('f32_up_33', 6, 32, 192, 32, 32, 'conv_transpose'),      # phases of 33 and 32 pixels: tiles of equal size
+    ('f32_up_rect', 5, 64, 136, 35, 48, 'conv_transpose'),
+]
+
+
+@pytest.mark.parametrize('case', WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_conv2d_float_large_layers(case):
+    """float32 layers with enough pixels for the float kernel's 512-pixel tiles, and polyphase layers whose phase
+    extents are no multiple of the tile: plain, with the fused epilogue, and with the style-gradient reduction."""
+    from ga_gan_amd import conv2d_plugin as cp
+    name, n, ci, co, h, w, kind = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn([n, ci, h, w], generator=g)
+    s = torch.randn([n, ci], generator=g) * 0.5 + 1
+    d = torch.rand([n, co], generator=g) + 0.5
+    b = torch.randn([co], generator=g)
+    if kind == 'conv':
+        wt = torch.randn([co, ci, 3, 3], generator=g) / (ci * 9) ** 0.5
+        conv = lambda t: F.conv2d(t, wt.double(), padding=1)
+        plan = cp.plan_conv(3, 3, padding=1)
+        packed = plan.pack(wt.to(DEV))
+    else:
+        wt = torch.randn([ci, co, 3, 3], generator=g) / (ci * 9) ** 0.5
+        conv = lambda t: F.conv_transpose2d(t, wt.double(), stride=2)
+        plan = cp.plan_conv_transpose(3, 3, stride=2)
+        packed = plan.pack(wt.to(DEV), transposed_layout=True)
+    oh, ow = plan.out_size(h, w)
+    noise = torch.randn([oh, ow], generator=g)
+    r = torch.randn([n, co, oh, ow], generator=g)
+    xd = x.to(DEV)
+    close(cp.conv2d(xd, packed, plan, co), conv(x.double()), ULP[torch.float32], name)
+    c = conv(x.double() * s.double().reshape(n, ci, 1, 1))
+    pre = c * d.double().reshape(n, co, 1, 1) + noise.double() * 0.7 + b.double().reshape(1, co, 1, 1)
+    want = (F.leaky_relu(pre, 0.2) * 1.4142).clamp(-2.0, 2.0)
+    y = cp.conv2d(xd, packed, plan, co, in_scale=s.to(DEV), out_scale=d.to(DEV), bias=b.to(DEV), noise=noise.to(DEV),
+                  noise_gain=torch.tensor(0.7, device=DEV), act='lrelu', alpha=0.2, gain=1.4142, clamp=2.0)
+    close(y, want, 2 * ULP[torch.float32], name + ' epilogue')
+    y, red = cp.conv2d(xd, packed, plan, co, in_scale=s.to(DEV), out_scale=d.to(DEV), reduce_x=r.to(DEV))
+    close(y, c * d.double().reshape(n, co, 1, 1), 2 * ULP[torch.float32], name + ' scaled')
+    close(red, (c * r.double()).sum([2, 3]), 4 * ULP[torch.float32], name + ' reduction')
+
+
 def test_conv2d_bench_shapes_match_library_conv():
     """Bench-size layers (256-config, batch 8) against the library convolution on the GPU in float32."""
     from ga_gan_amd import conv2d_plugin as cp
