@@ -7,8 +7,10 @@ This is the training-path `modulated_conv2d` + `bias_act` of a synthesis layer
 (reference: training/networks.py:640-653 and 919-921), a to-RGB layer (:961-962) and a
 discriminator `Conv2dLayer` (:748-760) without their intermediate tensors.  When a
 higher-order graph is being recorded (path-length and R1 regularisation) the backward re-expresses
-the layer with the differentiable primitive ops instead, so gradients of any order stay available.
+the layer with the differentiable primitive ops instead, so gradients of any order stay available; a forward pass
+that is known to be differentiated that way runs inside `differentiable_twice()` and skips the one-kernel form.
 """
+import contextlib
 import weakref
 
 import torch
@@ -75,6 +77,23 @@ def _one_pass_up(x, w, f, k, blur_pad, extra, act, alpha, gain):
         return None
     m, fy4 = taps
     return memo.memo(w, 'up2_fir', lambda: _layer.compose_up2_weights(w, m)), fy4
+
+
+_twice = False   # True inside differentiable_twice()
+
+
+@contextlib.contextmanager
+def differentiable_twice():
+    """Layers called inside run as the composite of differentiable primitive ops from the start.  For a forward pass
+    whose backward will be taken with `create_graph=True` (path-length and R1 regularisation): the one-kernel layer
+    would have to be evaluated a second time as that composite when its backward is asked for a graph."""
+    global _twice
+    old = _twice
+    _twice = True
+    try:
+        yield
+    finally:
+        _twice = old
 
 
 def _noise_plane(noise, dtype):
@@ -279,4 +298,6 @@ def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=N
         assert max(min(-px0, -px1), 0) == 0 and max(min(-py0, -py1), 0) == 0
         extra = _align_extra((x.shape[3] - 1) * up + k)
         cfg = ('up2', k, 2, 0, None, act, alpha, gain, clamp, (px0, px1 - extra, py0, py1), extra)
+    if _twice and torch.is_grad_enabled():
+        return _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
     return _FusedConv.apply(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)

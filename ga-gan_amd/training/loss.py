@@ -5,11 +5,14 @@ training/loss.py:69-152).  Gradient synchronisation across GPUs: where the refer
 around the forward pass whose backward is the phase's last one, this loss arms `grad_sync`
 (the trainer's GradReducer) right before that backward call, so that gradients are exchanged
 while the rest of the backward pass still runs."""
+import contextlib
+
 import numpy as np
 import torch
 
 from ..torch_utils import training_stats
 from ..torch_utils.ops import conv2d_gradfix
+from ..torch_utils.ops import fused_layer
 
 
 def _interleave(a, b, groups):
@@ -112,7 +115,8 @@ class StyleGAN2Loss(Loss):
         if do_Gpl:
             with torch.autograd.profiler.record_function('Gpl_forward'):
                 batch_size = gen_z.shape[0] // self.pl_batch_shrink
-                gen_img, gen_ws = self.run_G(gen_z[:batch_size], gen_c[:batch_size], sync=sync, set_w_requires_grad=True)
+                with fused_layer.differentiable_twice():
+                    gen_img, gen_ws = self.run_G(gen_z[:batch_size], gen_c[:batch_size], sync=sync, set_w_requires_grad=True)
                 unit = torch.randn_like(gen_img) if pl_noise_unit is None else pl_noise_unit
                 pl_noise = unit / np.sqrt(gen_img.shape[2] * gen_img.shape[3])
                 with torch.autograd.profiler.record_function('pl_grads'), conv2d_gradfix.no_weight_gradients():
@@ -171,7 +175,8 @@ class StyleGAN2Loss(Loss):
             name = 'Dreal_Dr1' if do_Dmain and do_Dr1 else 'Dreal' if do_Dmain else 'Dr1'
             with torch.autograd.profiler.record_function(name + '_forward'):
                 real_img_tmp = real_img.detach().requires_grad_(do_Dr1)
-                real_logits = self.run_D(real_img_tmp, real_c, sync=sync)
+                with fused_layer.differentiable_twice() if do_Dr1 else contextlib.nullcontext():
+                    real_logits = self.run_D(real_img_tmp, real_c, sync=sync)
                 training_stats.report('Loss/scores/real', real_logits)
                 training_stats.report('Loss/signs/real', real_logits.sign())
                 loss_Dreal = 0
