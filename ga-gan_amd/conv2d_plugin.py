@@ -255,6 +255,21 @@ def supports_mask(x, plan, co, out_hw=None, reduce=False):
     return bool(_lib.lib().sg_conv2d_supports_mask(ctypes.byref(p)))
 
 
+def kernel_name(x, plan, co, out_hw=None):
+    """Name of the device kernel `conv2d(x, ..., plan, co)` runs for a plain call (no scales, noise, reduction or mask),
+    as `sg_conv2d_kernel` reports it."""
+    n, ci, h, w = x.shape
+    oh, ow = plan.out_size(h, w) if out_hw is None else out_hw
+    p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(x), y=_lib.ptr(x), dtype=_lib.dtype_code(x), n=n, ci=ci, h=h, w_in=w, co=co,
+                     oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step, num_phases=len(plan.phases), act=1, gain=1.0,
+                     clamp=-1.0, mask_clamp=-1.0)
+    offset = 0
+    for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
+        p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
+        offset += nky * nkx * co * ci
+    return _lib.lib().sg_conv2d_kernel(ctypes.byref(p)).decode()
+
+
 class Conv2dWgradParams(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('g', ctypes.c_void_p), ('dw', ctypes.c_void_p),
                 ('x_scale', ctypes.c_void_p), ('g_scale', ctypes.c_void_p), ('dtype', ctypes.c_int32),

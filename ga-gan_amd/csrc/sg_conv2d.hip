@@ -1088,6 +1088,7 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
     SG_REQUIRE(p->mask_y == nullptr, SG_ERR_UNSUPPORTED, "conv2d: no kernel applies an input mask for this geometry");
     if (conv3x3_eligible(*p)) return conv3x3_launch(*p, (hipStream_t)stream);
     if (conv_up2_eligible(*p)) return conv_up2_launch(*p, (hipStream_t)stream);
+    if (pointwise_eligible(*p)) return pointwise_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
         case SG_F32: return launch<float>(*p, (hipStream_t)stream);
         case SG_F16: return launch<__half>(*p, (hipStream_t)stream);
@@ -1163,6 +1164,7 @@ extern "C" const char* sg_conv2d_kernel(const sg_conv2d_params* p) {
     if (sg::conv1x1_few_eligible(*p)) return "conv1x1_few_kernel";
     if (sg::band3x3_eligible(*p)) return "band3x3_kernel";
     if (sg::conv_up2_eligible(*p)) return "conv_up2_kernel";
+    if (sg::pointwise_eligible(*p)) return "pointwise_kernel";
     if (!sg::conv3x3_eligible(*p)) return "conv2d_mfma_kernel";
     return sg::conv3x3_resident(*p) ? "conv3x3_resident_kernel" : "conv3x3_kernel";
 }

@@ -40,6 +40,10 @@ int conv1x1_few_reduce_rows(const sg_conv2d_params& p);
 bool wgrad1x1_few_eligible(const sg_conv2d_wgrad_params& p);
 int wgrad1x1_few_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
 
+// 1x1 convolutions with 32 or more channels on both sides and no modulation, as a streaming matrix-core kernel (sg_pointwise.hip).
+bool pointwise_eligible(const sg_conv2d_params& p);
+int pointwise_launch(const sg_conv2d_params& p, hipStream_t stream);
+
 // Transposed 3x3 stride-2 convolution as one unit-stride contraction over the 2 x 2 input window (sg_convup.hip).
 bool conv_up2_eligible(const sg_conv2d_params& p);
 int conv_up2_launch(const sg_conv2d_params& p, hipStream_t stream);

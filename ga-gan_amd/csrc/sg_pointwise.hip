@@ -1,0 +1,240 @@
+// 1x1 convolution of 16-bit tensors with 32 or more channels on both sides: the residual skips of the discriminator
+// (a 1x1 contraction behind the down-sampling filter) and their data gradients.  Per image this is the product
+// Y[co][pixel] = W[co][ci] X[ci][pixel] with both planes row-major in memory, 20 .. 170 multiply-adds per byte moved:
+// bound by HBM, so the kernel is built around moving X once in and Y once out in whole, coalesced packets.
+//
+// A workgroup (4 waves) owns 256 consecutive pixels of one image's flattened planes and up to 128 output channels;
+// each wave 64 of the pixels.  GEMM view: M = pixels, N = output channels, K = input channels, 32 at a time:
+//   * the X chunk [32 channels][256 pixels] goes to LDS exactly as it lies in memory (16-byte copies, one channel row
+//     per 32 lanes) - no transposition in registers.  The matrix instruction wants 8 consecutive K values of one
+//     pixel per lane; ds_read_b64_tr_b16 delivers 4 channel rows x 16 pixels transposed, so a fragment is two such
+//     reads.  Rows are 544 bytes (32 modulo 256) and the K slots of lane group g are channels 4g .. 4g+3 and
+//     16+4g .. 16+4g+3, so that the 8 rows a 32-lane half reads are consecutive: no bank conflicts;
+//   * the W chunk [channels out][32 channels in] is staged in that K order (each 16-byte piece of a weight row lands
+//     as two 8-byte halves), 64-byte rows with the 16-byte slots XOR-swizzled;
+//   * the next chunk's packets are requested before the multiplies of the current one and written to the other LDS
+//     buffer after them: one barrier per chunk.
+// A lane ends up with 4 consecutive pixels of one output channel per accumulator and stores them as 8 bytes after
+// bias, leaky ReLU, gain and clamp.  Workgroups that share a pixel tile (more than 128 output channels) follow each
+// other on one XCD, so the tile's second reading comes from that XCD's L2.
+#include "sg_common.h"
+#include "sg_conv3x3.h"
+
+namespace sg {
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int TP = 256;                 // pixels per workgroup
+constexpr int KCH = 32;                 // input channels per chunk
+constexpr int kXPitch = TP * 2 + 32;    // bytes per channel row of the staged X chunk
+constexpr int kXBytes = KCH * kXPitch;  // 17408
+constexpr int kWRow = 64;               // bytes per staged weight row
+
+struct PwArgs {
+    const void* x; const void* w; void* y; const void* bias;
+    int n, ci, co;
+    int64_t hw;           // pixels per plane, a multiple of 8
+    int tiles_img;        // pixel tiles per image
+    int64_t tiles;        // pixel tiles in all
+    int cblocks;          // output-channel blocks
+    float slope, gain, hi;
+};
+
+template <class T> struct Mma16;
+template <> struct Mma16<__hip_bfloat16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<__half> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int wswz(int row, int slot) { return row * kWRow + (((slot ^ (row >> 1)) & 3) << 4); }
+
+__device__ __forceinline__ uint2 read_tr(const unsigned char* p) {
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p)));
+}
+
+template <class T> __device__ __forceinline__ unsigned pack2(float a, float b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(a)) |
+           ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
+}
+
+template <class T, int NTL>   // NTL: 16-channel output tiles per workgroup
+__global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(PwArgs a) {
+    constexpr int BN = 16 * NTL;
+    constexpr int W_IT = (BN * 4 + kThreads - 1) / kThreads;   // 16-byte weight pieces per lane and chunk
+    constexpr int kWBytes = BN * kWRow;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+
+    // workgroup -> (pixel tile, channel block): the blocks of a tile are neighbours on one XCD
+    const int64_t u = blockIdx.x;
+    const int xcd = (int)(u & 7);
+    const int64_t v = u >> 3;
+    const int cb = (int)(v % a.cblocks);
+    const int64_t tile = (v / a.cblocks) * 8 + xcd;
+    if (tile >= a.tiles) return;
+    const int img = (int)(tile / a.tiles_img);
+    const int64_t p0 = (tile % a.tiles_img) * TP;
+    const int co0 = cb * BN;
+    const int chunks = a.ci / KCH;
+    const int nbuf = chunks > 1 ? 2 : 1;
+
+    unsigned char* s_x[2] = {smem, smem + (nbuf - 1) * kXBytes};
+    unsigned char* s_w[2] = {smem + nbuf * kXBytes, smem + nbuf * kXBytes + (nbuf - 1) * kWBytes};
+
+    const T* __restrict__ x = (const T*)a.x;
+    const T* __restrict__ w = (const T*)a.w;
+
+    // ---- staging plan -----------------------------------------------------------------------------------------
+    const int xrow = tid >> 5, xpk = tid & 31;                      // channel row (of 8 per pass) and 8-pixel packet
+    const bool x_ok = p0 + xpk * 8 < a.hw;
+    const T* x_src = x + ((int64_t)img * a.ci + xrow) * a.hw + p0 + xpk * 8;
+    uint4 xreg[4], wreg[W_IT];
+    auto load = [&](int c) __attribute__((always_inline)) {
+        const int c0 = c * KCH;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            xreg[it] = make_uint4(0, 0, 0, 0);
+            if (x_ok) xreg[it] = *reinterpret_cast<const uint4*>(x_src + (int64_t)(c0 + it * 8) * a.hw);
+        }
+#pragma unroll
+        for (int k = 0; k < W_IT; k++) {
+            const int e = tid + k * kThreads, row = e >> 2, q = e & 3;
+            wreg[k] = make_uint4(0, 0, 0, 0);
+            if (e < BN * 4 && co0 + row < a.co) wreg[k] = *reinterpret_cast<const uint4*>(w + (int64_t)(co0 + row) * a.ci + c0 + q * 8);
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 4; it++)
+            *reinterpret_cast<uint4*>(s_x[buf] + (it * 8 + xrow) * kXPitch + xpk * 16) = xreg[it];
+#pragma unroll
+        for (int k = 0; k < W_IT; k++) {
+            const int e = tid + k * kThreads, row = e >> 2, q = e & 3;
+            if (e < BN * 4) {
+                // piece q holds channels 8q .. 8q+7: groups 2q and 2q+1 of four; group h is K slot (h & 3, h >> 2)
+                const int h0 = 2 * q, h1 = 2 * q + 1;
+                *reinterpret_cast<uint2*>(s_w[buf] + wswz(row, h0 & 3) + (h0 >> 2) * 8) = make_uint2(wreg[k].x, wreg[k].y);
+                *reinterpret_cast<uint2*>(s_w[buf] + wswz(row, h1 & 3) + (h1 >> 2) * 8) = make_uint2(wreg[k].z, wreg[k].w);
+            }
+        }
+    };
+
+    f32x4_t acc[4][NTL];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < NTL; j++) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // this lane's addresses: transposing reads (lane 4q+p of a 16-lane group supplies row q, pixels 4p .. 4p+3)
+    const int a_off = (4 * lgrp + (lrow >> 2)) * kXPitch + (wave * 64 + (lrow & 3) * 4) * 2;
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        uint4 af[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint2 lo = read_tr(s_x[buf] + a_off + t * 32);
+            const uint2 hi = read_tr(s_x[buf] + a_off + t * 32 + 16 * kXPitch);
+            af[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; j++) {
+            const uint4 bf = *reinterpret_cast<const uint4*>(s_w[buf] + wswz(j * 16 + lrow, lgrp));
+#pragma unroll
+            for (int t = 0; t < 4; t++) Mma16<T>::run(af[t], bf, acc[t][j]);
+        }
+    };
+
+    load(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < chunks; c++) {
+        if (c + 1 < chunks) load(c + 1);
+        multiply(c & 1);
+        if (c + 1 < chunks) commit((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: rows 4 lgrp .. 4 lgrp + 3 of tile t are 4 consecutive pixels, the column is the channel ------------
+    T* __restrict__ y = (T*)a.y;
+    const int64_t px0 = p0 + wave * 64 + lgrp * 4;
+#pragma unroll
+    for (int j = 0; j < NTL; j++) {
+        const int ch = co0 + j * 16 + lrow;
+        if (ch >= a.co) continue;
+        const float bs = a.bias ? Elem<T>::load(((const T*)a.bias)[ch]) : 0.f;
+        T* dst = y + ((int64_t)img * a.co + ch) * a.hw;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int64_t px = px0 + t * 16;
+            if (px >= a.hw) continue;
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float z = acc[t][j][e] + bs;
+                z = (z > 0.f) ? z : z * a.slope;
+                r[e] = fminf(fmaxf(z * a.gain, -a.hi), a.hi);
+            }
+            *reinterpret_cast<uint2*>(dst + px) = make_uint2(pack2<T>(r[0], r[1]), pack2<T>(r[2], r[3]));
+        }
+    }
+}
+
+template <class T, int NTL>
+int launch_tiles(const PwArgs& a, hipStream_t stream) {
+    const int chunks = a.ci / KCH, nbuf = chunks > 1 ? 2 : 1;
+    const size_t lds = (size_t)nbuf * (kXBytes + 16 * NTL * kWRow);
+    const int64_t groups = (a.tiles + 7) / 8 * 8 * a.cblocks;
+    SG_REQUIRE(groups <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
+    hipLaunchKernelGGL((pointwise_kernel<T, NTL>), dim3((unsigned)groups), dim3(kThreads), lds, stream, a);
+    return check_launch("sg_conv2d (pointwise)");
+}
+
+template <class T>
+int launch_pointwise(const sg_conv2d_params& p, hipStream_t stream) {
+    PwArgs a;
+    a.x = p.x; a.w = p.w; a.y = p.y; a.bias = p.bias;
+    a.n = p.n; a.ci = p.ci; a.co = p.co;
+    a.hw = (int64_t)p.h * p.w_in;
+    a.tiles_img = (int)((a.hw + TP - 1) / TP);
+    a.tiles = (int64_t)a.tiles_img * p.n;
+    a.slope = (p.act == 3) ? p.alpha : 1.f;
+    a.gain = p.gain;
+    a.hi = (p.clamp >= 0.f) ? p.clamp : __builtin_huge_valf();
+    if (p.co <= 32) { a.cblocks = 1; return launch_tiles<T, 2>(a, stream); }
+    if (p.co <= 64) { a.cblocks = 1; return launch_tiles<T, 4>(a, stream); }
+    a.cblocks = (p.co + 127) / 128;
+    return launch_tiles<T, 8>(a, stream);
+}
+
+}  // namespace
+
+bool pointwise_eligible(const sg_conv2d_params& p) {
+    if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
+    if (p.num_phases != 1 || p.in_step != 1 || p.out_step != 1) return false;
+    const sg_conv2d_phase& ph = p.phase[0];
+    if (ph.nky != 1 || ph.nkx != 1 || ph.oy0 != 0 || ph.ox0 != 0 || ph.dy0 != 0 || ph.dx0 != 0 || ph.w_offset != 0) return false;
+    if (p.oh != p.h || p.ow != p.w_in) return false;
+    if (p.in_scale || p.out_scale || p.noise || p.reduce_x || p.mask_y) return false;
+    if (p.ci < 32 || p.ci % KCH != 0 || p.co < 16) return false;
+    const int64_t hw = (int64_t)p.h * p.w_in;
+    if (hw % 8 != 0 || hw < 1024) return false;
+    return aligned16(p.x) && aligned16(p.y) && aligned16(p.w);
+}
+
+int pointwise_launch(const sg_conv2d_params& p, hipStream_t stream) {
+    return (p.dtype == SG_BF16) ? launch_pointwise<__hip_bfloat16>(p, stream) : launch_pointwise<__half>(p, stream);
+}
+
+}  // namespace sg

@@ -270,8 +270,9 @@ int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t 
  * input step 1 or 2), "conv3x3_resident_kernel" (the same with at most 64 channels on both sides: the weights
  * stay in LDS), "conv_up2_kernel" (3x3 transposed, stride 2, no epilogue), "band3x3_kernel" (3x3 same-size, 32 input
  * and 32 or 64 output channels: persistent row bands with the weights in registers), "conv1x1_few_kernel" (1x1 with at
- * most 4 channels on one side, planes of at least 4096 pixels: streaming kernels on the vector units);
- * "conv2d_mfma_kernel" otherwise.
+ * most 4 channels on one side, planes of at least 4096 pixels: streaming kernels on the vector units),
+ * "pointwise_kernel" (1x1 with 32 or more channels on both sides, no modulation, noise, reduction or mask: the
+ * residual skips of the discriminator); "conv2d_mfma_kernel" otherwise.
  * Static storage. */
 const char* sg_conv2d_kernel(const sg_conv2d_params* p);
 

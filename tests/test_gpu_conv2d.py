@@ -153,6 +153,40 @@ def test_conv2d_float_large_layers(case):
     close(red, (c * r.double()).sum([2, 3]), 4 * ULP[torch.float32], name + ' reduction')
 
 
+POINTWISE_CASES = [  # name, n, ci, co, h, w: 1x1 layers with 32 or more channels on both sides (the streaming kernel)
+    ('pw_32_64', 3, 32, 64, 64, 64),
+    ('pw_64_32', 2, 64, 32, 48, 40),            # a last tile of 128 pixels
+    ('pw_64_128', 5, 64, 128, 40, 40),          # 1600 pixels: ragged last tile; more tiles than a multiple of eight
+    ('pw_96_48', 2, 96, 48, 32, 36),
+    ('pw_128_200', 2, 128, 200, 36, 32),        # two channel blocks, the second partly filled
+    ('pw_256_512', 1, 256, 512, 32, 32),        # eight chunks, four channel blocks
+]
+
+
+@pytest.mark.parametrize('case', POINTWISE_CASES, ids=[c[0] for c in POINTWISE_CASES])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv2d_pointwise(case, dtype):
+    from ga_gan_amd import conv2d_plugin as cp
+    name, n, ci, co, h, w = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn([n, ci, h, w], generator=g).to(dtype)
+    wt = (torch.randn([co, ci, 1, 1], generator=g) / ci ** 0.5).to(dtype)
+    b = torch.randn([co], generator=g).to(dtype)
+    plan = cp.plan_conv(1, 1)
+    packed = plan.pack(wt.to(DEV))
+    assert cp.kernel_name(x.to(DEV), plan, co) == 'pointwise_kernel'
+    c = F.conv2d(x.double(), wt.double())
+    close(cp.conv2d(x.to(DEV), packed, plan, co, gain=0.5 ** 0.5), c * 0.5 ** 0.5, ULP[dtype], name)
+    want = (F.leaky_relu(c + b.double().reshape(1, co, 1, 1), 0.2) * 1.4142).clamp(-1.5, 1.5)
+    y = cp.conv2d(x.to(DEV), packed, plan, co, bias=b.to(DEV), act='lrelu', alpha=0.2, gain=1.4142, clamp=1.5)
+    close(y, want, 2 * ULP[dtype], name + ' epilogue')
+    # the data gradient of such a layer is the same kernel with the weights transposed
+    plan_t = cp.plan_conv_transpose(1, 1, stride=1)
+    gy = torch.randn([n, co, h, w], generator=g).to(dtype)
+    dx = cp.conv2d(gy.to(DEV), plan_t.pack(wt.to(DEV), transposed_layout=True), plan_t, ci)
+    close(dx, F.conv_transpose2d(gy.double(), wt.double()), ULP[dtype], name + ' transposed')
+
+
 def test_conv2d_bench_shapes_match_library_conv():
     """Bench-size layers (256-config, batch 8) against the library convolution on the GPU in float32."""
     from ga_gan_amd import conv2d_plugin as cp
