@@ -302,10 +302,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
 // intensity puts them at or near the HBM roofline): the whole weight tensor (<= 72 KB) stays in LDS for the
 // lifetime of a persistent workgroup, which then only streams pixel tiles: all input channels of the next tile
 // are loaded into registers while the current tile is multiplied, and the epilogue's operands are loaded ahead of
-// the multiply phase.  CHUNKS = ceil(ci / 32), M_TILES = ceil(co / 16).  Unit stride only.
-template <class T, int CHUNKS, int M_TILES>
-__global__ void __launch_bounds__(kThreads, (CHUNKS == 1) ? 2 : 1) conv3x3_resident_kernel(Conv3x3Args g, int units) {
-    using G = Geo<1>;
+// the multiply phase.  CHUNKS = ceil(ci / 32), M_TILES = ceil(co / 16).  STEP = 2 (one chunk only: the strided
+// layer behind the blur of the discriminator's first block, 32 -> 64 channels) has the LDS of a CU to itself; the
+// general kernel would run it one tile per workgroup with nothing in flight while it multiplies.
+template <class T, int CHUNKS, int M_TILES, int STEP = 1>
+__global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1) ? 2 : 1) conv3x3_resident_kernel(Conv3x3Args g, int units) {
+    using G = Geo<STEP>;
     constexpr int NV = G::NV, LWP = G::LWP, BMW = 16 * M_TILES;
     constexpr int kWChunk = 9 * BMW * kRow;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1) ? 2 : 1) conv3x3_resid
             for (int q = 0; q < G::STEPS; q++) {
                 const int item = slot0 + 16 * q;
                 const int ry = item / NV, v = item - ry * NV;
-                const int iy = a0 + g.dy0 + ry, px0 = b0 + g.px_shift + v * 8;
+                const int iy = a0 * STEP + g.dy0 + ry, px0 = b0 * STEP + g.px_shift + v * 8;
                 va[ch][q] = make_uint4(0, 0, 0, 0);
                 vb[ch][q] = make_uint4(0, 0, 0, 0);
                 if (c_ok && item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1) ? 2 : 1) conv3x3_resid
 
     int brow[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * LWP + (j & 1) * 16 + lrow + g.px_col;
+    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * STEP * LWP + ((j & 1) * 16 + lrow) * STEP + g.px_col;
     const int a_lane = lrow * kRow + (((lgrp ^ (lrow >> 1)) & 3) << 4);
     const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
     const int ch0 = lrow;
@@ -528,7 +530,8 @@ bool conv3x3_eligible(const sg_conv2d_params& p) {
 }
 
 bool conv3x3_resident(const sg_conv2d_params& p) {   // among the eligible geometries: the weights-resident kernel
-    return p.in_step == 1 && p.ci <= 2 * KCH && p.co <= BM;
+    if (p.in_step == 2) return p.ci <= KCH && p.co <= BM && p.co > 32;
+    return p.ci <= 2 * KCH && p.co <= BM;
 }
 
 int conv3x3_reduce_rows(const sg_conv2d_params& p) {
@@ -547,10 +550,11 @@ int compute_units() {   // of the current device; asked once per process and dev
     return cu;
 }
 
-template <class T, int CHUNKS, int M_TILES>
+template <class T, int CHUNKS, int M_TILES, int STEP = 1>
 static int launch_resident(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
-    constexpr size_t lds = (size_t)CHUNKS * (9 * 16 * M_TILES * kRow + Geo<1>::kInBytes);
-    auto kernel = conv3x3_resident_kernel<T, CHUNKS, M_TILES>;
+    constexpr size_t lds = (size_t)CHUNKS * (9 * 16 * M_TILES * kRow + Geo<STEP>::kInBytes);
+    static_assert(lds <= 160 * 1024, "weights and tile do not fit the LDS of a CU");
+    auto kernel = conv3x3_resident_kernel<T, CHUNKS, M_TILES, STEP>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     const int per_cu = (CHUNKS == 1) ? std::min<int>(2, (int)((160 * 1024) / lds)) : 1;
@@ -560,7 +564,8 @@ static int launch_resident(const Conv3x3Args& g, int64_t units, hipStream_t stre
 }
 
 template <class T>
-static int launch_resident_for(const Conv3x3Args& g, int64_t units, int ci, int co, hipStream_t stream) {
+static int launch_resident_for(const Conv3x3Args& g, int64_t units, int ci, int co, int step, hipStream_t stream) {
+    if (step == 2) return launch_resident<T, 1, 4, 2>(g, units, stream);
     const bool one = ci <= KCH, narrow = co <= 32;
     if (one) return narrow ? launch_resident<T, 1, 2>(g, units, stream) : launch_resident<T, 1, 4>(g, units, stream);
     return narrow ? launch_resident<T, 2, 2>(g, units, stream) : launch_resident<T, 2, 4>(g, units, stream);
@@ -611,8 +616,8 @@ int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
     SG_REQUIRE(units <= INT32_MAX - 8, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     g.units = (int)units;
     if (conv3x3_resident(p))
-        return (p.dtype == SG_BF16) ? launch_resident_for<__hip_bfloat16>(g, units, p.ci, p.co, stream)
-                                    : launch_resident_for<__half>(g, units, p.ci, p.co, stream);
+        return (p.dtype == SG_BF16) ? launch_resident_for<__hip_bfloat16>(g, units, p.ci, p.co, p.in_step, stream)
+                                    : launch_resident_for<__half>(g, units, p.ci, p.co, p.in_step, stream);
     if (p.dtype == SG_BF16) return launch_wide_or_not<__hip_bfloat16>(g, p.in_step, stream);
     return launch_wide_or_not<__half>(g, p.in_step, stream);
 }
