@@ -2,9 +2,13 @@
 `upfirdn2d_plugin` (torch_utils/ops/upfirdn2d.cpp:16, bound at :98-101), executed by
 the gfx950 kernel behind `sg_upfirdn2d`.  Errors surface as RuntimeError, as the
 reference's TORCH_CHECKs do (upfirdn2d.cpp:19-36)."""
+import os
+
 import torch
 
 from . import _lib
+
+_DETAIL = bool(os.environ.get('SG_PROFILE_DETAIL'))   # geometry in the profiling labels
 
 
 def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
@@ -54,5 +58,7 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
         label = 'upfirdn2d_blur4_kernel'
     else:
         label = f'upfirdn2d_tiled_kernel<up{upx} down{downx}>' if tiled else 'upfirdn2d_generic_kernel'
+    if _DETAIL:
+        label += f' {c}x{h}x{w} n{n} {str(x.dtype)[6:]}'
     _lib.launch('sg_upfirdn2d', p, x, label, _lib.nbytes(x, y))
     return y

@@ -241,6 +241,9 @@ WGRAD_CASES = [  # name, n, ci, co, h, w, k, stride, padding
     ('3x3_96_96', 2, 96, 96, 16, 32, 3, 1, 1),
     ('3x3_stride2_32_32', 2, 32, 32, 16, 64, 3, 2, 1),
     ('3x3_stride2_32_96', 2, 32, 96, 24, 64, 3, 2, 1),
+    ('3x3_stride2_g16', 5, 64, 96, 40, 40, 3, 2, 0),            # gradient planes 19 x 19 / 16 columns wide: half-filled tiles
+    ('3x3_stride2_g16b', 4, 64, 64, 33, 40, 3, 2, 0),
+    ('3x3_g16', 3, 64, 64, 12, 16, 3, 1, 1),
 ]
 
 

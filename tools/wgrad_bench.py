@@ -26,6 +26,7 @@ LAYERS += [(512, 512, 64, torch.float32), (512, 512, 32, torch.float32)]
 LAYERS += [(32, 32, 1024, torch.bfloat16), (64, 64, 512, torch.bfloat16)]   # 8, 9
 LAYERS_STRIDED = [(64, 128, -264, torch.bfloat16), (128, 256, -136, torch.bfloat16), (256, 512, -72, torch.bfloat16)]   # h < 0: stride 2, input h x h
 LAYERS += LAYERS_STRIDED
+LAYERS += [(512, 512, -40, torch.bfloat16), (512, 512, 16, torch.bfloat16)]   # 13, 14: gradient planes of 16 x 16
 if os.environ.get('ONLY'):
     LAYERS = [LAYERS[int(i)] for i in os.environ['ONLY'].split(',')]
 for ci, co, h, dtype in LAYERS:
