@@ -247,8 +247,20 @@ struct FewWgradArgs {
     float m_slope, m_hi;
 };
 
+// Each wave owns (sample, chunk of pixels, 32 many-side channels) and walks the chunk 128 pixels at a time.  The
+// packets of a step are requested row by row - 16 lanes read 256 contiguous bytes of one channel plane, four planes
+// per instruction - masked in registers, and parked in a wave-private LDS image [channel][128 pixels] (272-byte rows),
+// from which every lane takes the fragments of its own channel: 8 consecutive pixels are 16 contiguous bytes.  (Read
+// straight from memory, a lane per channel plane, the same fragments cost 32 scattered 32-byte requests per
+// instruction and ran at 1.3 - 2.5 TB/s.)  The next step's packets are in flight while this one is multiplied.
+constexpr int kWgSP = 16;                         // packets (of 8 pixels) per step
+constexpr int kWgPitch = kWgSP * 16 + 16;         // bytes per LDS row
+constexpr int kWgRows = 32 + 4;                   // many-side rows, few-side rows
+constexpr int kWgWaveBytes = kWgRows * kWgPitch;  // 9792
+
 template <class T, bool MASK>
 __global__ void __launch_bounds__(256) wgrad1x1_few_kernel(FewWgradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_wg[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lc = lane & 31, hh = lane >> 5;
     int unit = blockIdx.x * 4 + wave;                      // (sample, chunk) of this wave
@@ -256,42 +268,89 @@ __global__ void __launch_bounds__(256) wgrad1x1_few_kernel(FewWgradArgs g) {
     if (unit >= g.n * g.chunks) return;
     const int n = unit / g.chunks, chunk = unit - n * g.chunks;
     const int64_t plane = (int64_t)g.packets * 8;
-    const int cm = mblk * 32 + lc;
-    const bool m_ok = cm < g.cm, f_ok = lc < g.cf;
-    const T* __restrict__ pm = (const T*)g.many + ((int64_t)n * g.cm + min(cm, g.cm - 1)) * plane;
-    const T* __restrict__ pf = (const T*)g.few + ((int64_t)n * g.cf + min(lc, g.cf - 1)) * plane;
-    const T* __restrict__ pmask = nullptr;
-    if constexpr (MASK) pmask = g.mask_on_many ? (const T*)g.mask_y + ((int64_t)n * g.cm + min(cm, g.cm - 1)) * plane
-                                               : (const T*)g.mask_y + ((int64_t)n * g.cf + min(lc, g.cf - 1)) * plane;
+    unsigned char* s_many = s_wg + wave * kWgWaveBytes;
+    unsigned char* s_few = s_many + 32 * kWgPitch;
     const int pk0 = chunk * g.chunk, pk1 = min(g.packets, pk0 + g.chunk);
+
+    // staging plan: item k of the many side is channel 4 k + (lane >> 4), packet lane & 15; the few side is one item
+    const int srow = lane >> 4, spk = lane & 15;
+    const T* __restrict__ pm = (const T*)g.many + ((int64_t)n * g.cm + mblk * 32) * plane;
+    const T* __restrict__ pf = (const T*)g.few + (int64_t)n * g.cf * plane;
+    const T* __restrict__ pmask_m = nullptr;
+    const T* __restrict__ pmask_f = nullptr;
+    if constexpr (MASK) {
+        if (g.mask_on_many) pmask_m = (const T*)g.mask_y + ((int64_t)n * g.cm + mblk * 32) * plane;
+        else pmask_f = (const T*)g.mask_y + (int64_t)n * g.cf * plane;
+    }
+    const int rows_m = min(32, g.cm - mblk * 32);
+    uint4 va[8], vm[MASK ? 8 : 1], vf, vfm;
+    auto load = [&](int pp) __attribute__((always_inline)) {
+        const int p = pp + spk;
+        const bool p_ok = p < pk1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int row = 4 * k + srow;
+            va[k] = make_uint4(0, 0, 0, 0);
+            if constexpr (MASK) vm[k] = make_uint4(0, 0, 0, 0);
+            if (p_ok && row < rows_m) {
+                va[k] = *reinterpret_cast<const uint4*>(pm + row * plane + (int64_t)p * 8);
+                if constexpr (MASK) {
+                    if (pmask_m) vm[k] = *reinterpret_cast<const uint4*>(pmask_m + row * plane + (int64_t)p * 8);
+                }
+            }
+        }
+        vf = make_uint4(0, 0, 0, 0);
+        vfm = make_uint4(0, 0, 0, 0);
+        if (p_ok && srow < g.cf) {
+            vf = *reinterpret_cast<const uint4*>(pf + srow * plane + (int64_t)p * 8);
+            if constexpr (MASK) {
+                if (pmask_f) vfm = *reinterpret_cast<const uint4*>(pmask_f + srow * plane + (int64_t)p * 8);
+            }
+        }
+    };
+    auto park = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if constexpr (MASK) {
+                if (pmask_m) {
+                    float f[8];
+                    unpack8<T>(va[k], f);
+                    mask8<T>(f, vm[k], g.m_slope, g.m_hi);
+                    va[k] = pack8<T>(f);
+                }
+            }
+            *reinterpret_cast<uint4*>(s_many + (4 * k + srow) * kWgPitch + spk * 16) = va[k];
+        }
+        if constexpr (MASK) {
+            if (pmask_f) {
+                float f[8];
+                unpack8<T>(vf, f);
+                mask8<T>(f, vfm, g.m_slope, g.m_hi);
+                vf = pack8<T>(f);
+            }
+        }
+        *reinterpret_cast<uint4*>(s_few + srow * kWgPitch + spk * 16) = vf;
+    };
+
     f32x16_t acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    // K step = 16 pixels: lane half hh takes packet 2 s + hh of both operands (the K order is free as long as both agree)
-    constexpr int U = 4;
-    for (int pp = pk0; pp < pk1; pp += 2 * U) {      // uniform trip count: the matrix instruction runs on all lanes
-        uint4 a[U], b[U], m[MASK ? U : 1];
+    const unsigned char* a_src = s_many + lc * kWgPitch + hh * 16;
+    const unsigned char* b_src = s_few + (lc & 3) * kWgPitch + hh * 16;
+    const bool f_ok = lc < g.cf;
+    load(pk0);
+    for (int pp = pk0; pp < pk1; pp += kWgSP) {      // uniform trip count: the matrix instruction runs on all lanes
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the previous step are done
+        park();
+        if (pp + kWgSP < pk1) load(pp + kWgSP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its writes have landed (the image is the wave's own)
+        // K step = 16 pixels: lane half hh takes packet 2 s + hh of both operands (the K order is free as long as both agree)
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int p = pp + 2 * u + hh;
-            const bool ok = p < pk1;
-            a[u] = make_uint4(0, 0, 0, 0);
-            b[u] = make_uint4(0, 0, 0, 0);
-            if (ok && m_ok) a[u] = *reinterpret_cast<const uint4*>(pm + (int64_t)p * 8);
-            if (ok && f_ok) b[u] = *reinterpret_cast<const uint4*>(pf + (int64_t)p * 8);
-            if constexpr (MASK) {
-                m[u] = make_uint4(0, 0, 0, 0);
-                if (ok && (g.mask_on_many ? m_ok : f_ok)) m[u] = *reinterpret_cast<const uint4*>(pmask + (int64_t)p * 8);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if constexpr (MASK) {
-                float f[8];
-                if (g.mask_on_many) { unpack8<T>(a[u], f); mask8<T>(f, m[u], g.m_slope, g.m_hi); a[u] = pack8<T>(f); }
-                else { unpack8<T>(b[u], f); mask8<T>(f, m[u], g.m_slope, g.m_hi); b[u] = pack8<T>(f); }
-            }
-            Pair<T>::mma(a[u], b[u], acc);      // rows: many-side channel, columns: few-side channel
+        for (int s2 = 0; s2 < kWgSP / 2; s2++) {
+            const uint4 a = *reinterpret_cast<const uint4*>(a_src + s2 * 32);
+            uint4 b = *reinterpret_cast<const uint4*>(b_src + s2 * 32);
+            if (!f_ok) b = make_uint4(0, 0, 0, 0);
+            Pair<T>::mma(a, b, acc);      // rows: many-side channel, columns: few-side channel
         }
     }
     // accumulator register e of lane (column lc, half hh): row (e & 3) + 8 (e >> 2) + 4 hh
@@ -423,7 +482,9 @@ int wgrad1x1_few_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
     g.cf = std::min(p.cx, p.cg);
     g.packets = (int)((int64_t)p.h * p.w_in / 8);
     g.chunk = 2048;                                   // 16384 pixels per wave
-    while (g.chunk > 64 && (int64_t)p.n * ((g.packets + g.chunk - 1) / g.chunk) < 4 * 1024) g.chunk /= 2;
+    // enough waves to fill the chip, no more: every wave ends with 16 x cf atomic adds to the same few addresses
+    const int64_t mblocks = (std::max(p.cx, p.cg) + 31) / 32;
+    while (g.chunk > 64 && (int64_t)p.n * ((g.packets + g.chunk - 1) / g.chunk) * mblocks < 2 * 1024) g.chunk /= 2;
     g.chunks = (g.packets + g.chunk - 1) / g.chunk;
     g.many_is_g = many_is_g ? 1 : 0;
     g.mask_on_many = many_is_g ? 1 : 0;               // the mask belongs to the gradient operand
@@ -432,11 +493,11 @@ int wgrad1x1_few_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
     const int64_t units = (int64_t)p.n * g.chunks;
     const dim3 grid((unsigned)((units + 3) / 4), (unsigned)((g.cm + 31) / 32));
     if (p.dtype == SG_BF16) {
-        if (p.mask_y) hipLaunchKernelGGL((wgrad1x1_few_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((wgrad1x1_few_kernel<__hip_bfloat16, false>), grid, dim3(256), 0, stream, g);
+        if (p.mask_y) hipLaunchKernelGGL((wgrad1x1_few_kernel<__hip_bfloat16, true>), grid, dim3(256), 4 * kWgWaveBytes, stream, g);
+        else hipLaunchKernelGGL((wgrad1x1_few_kernel<__hip_bfloat16, false>), grid, dim3(256), 4 * kWgWaveBytes, stream, g);
     } else {
-        if (p.mask_y) hipLaunchKernelGGL((wgrad1x1_few_kernel<__half, true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((wgrad1x1_few_kernel<__half, false>), grid, dim3(256), 0, stream, g);
+        if (p.mask_y) hipLaunchKernelGGL((wgrad1x1_few_kernel<__half, true>), grid, dim3(256), 4 * kWgWaveBytes, stream, g);
+        else hipLaunchKernelGGL((wgrad1x1_few_kernel<__half, false>), grid, dim3(256), 4 * kWgWaveBytes, stream, g);
     }
     return check_launch("sg_conv2d_wgrad");
 }
