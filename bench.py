@@ -46,6 +46,10 @@ CONFIGS = {
 }
 
 
+# Counter passes of a profiler that serialises every dispatch: keep the queue short (the figure such a run prints is not a result).
+SYNC_EVERY_STEP = bool(os.environ.get('SG_BENCH_SYNC_STEPS'))
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -269,6 +273,8 @@ def run_workload(args, config, steps, warmup, rank, world, local_rank, note, wit
     t0 = time.perf_counter()
     for _ in range(steps):
         trainer.step(real, real_c)
+        if SYNC_EVERY_STEP:
+            torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -361,7 +361,8 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         const int64_t x_plane8 = (int64_t)p.h * p.w_in * 8;   // 16-byte units from one chunk of a sample to the next
         const int chunks = t.chunks, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
         const int cb_begin = ksplit * chunks_per_split, cb_end = min(chunks, cb_begin + chunks_per_split);
-        uint4 wreg_a[W_IT], wreg_b[W_IT], xreg[X_IT];
+        constexpr bool ONE_AHEAD = PX != kPixels;
+        uint4 wreg_a[W_IT], wreg_b[ONE_AHEAD ? 1 : W_IT], xreg[X_IT];
         auto w_load = [&](uint4 (&wreg)[W_IT], int cb, int g0) {
             const int gtaps = min(kSplitTaps, taps - g0);
 #pragma unroll
@@ -425,7 +426,8 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             }
         };
         // Stage = (chunk, tap group).  The weights of a stage are requested two stages ahead (two register sets
-        // used in turn) and written to the LDS buffer the current stage does not read, after its multiplies; the
+        // used in turn; one stage ahead with one set in the wide tile, whose stages are twice as long and which has
+        // no registers to spare) and written to the LDS buffer the current stage does not read, after its multiplies; the
         // footprint of the next chunk is requested at the first stage of the current one and written - to a second
         // footprint buffer when LDS has room for it (t.x_double), else after one more barrier - at its last stage.
         // One barrier per stage: a wave's LDS writes and address arithmetic overlap the other waves' multiplies.
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         if (cb < cb_end) {
             w_load(wreg_a, cb, g0);
             x_load(cb);
-            w_load(wreg_b, cb1, g1);
+            if constexpr (!ONE_AHEAD) w_load(wreg_b, cb1, g1);
 #ifndef BAND_ABL_NOSTAGE
             x_commit(s_x[cb & 1], cb);
             w_commit(wreg_a, s_wb[0], g0);
@@ -456,7 +458,8 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         // after it and `far` is free: it receives the request for two stages on.
         auto stage = [&](uint4 (&next)[W_IT], uint4 (&far)[W_IT]) {
             const bool first = g0 == 0, last = cb1 != cb;
-            w_load(far, cb2, g2);
+            if constexpr (ONE_AHEAD) w_load(next, cb1, g1);
+            else w_load(far, cb2, g2);
             if (first && cb + 1 < cb_end) x_load(cb + 1);
 #ifndef BAND_ABL_NOCOMPUTE
             split_multiply(s_wb[sidx & 1], s_x[cb & 1], g0, min(kSplitTaps, taps - g0));
@@ -477,9 +480,13 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             sidx++;
         };
         while (cb < cb_end) {
-            stage(wreg_b, wreg_a);
-            if (cb >= cb_end) break;
-            stage(wreg_a, wreg_b);
+            if constexpr (ONE_AHEAD) {
+                stage(wreg_a, wreg_a);
+            } else {
+                stage(wreg_b, wreg_a);
+                if (cb >= cb_end) break;
+                stage(wreg_a, wreg_b);
+            }
         }
     }
     const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
