@@ -53,6 +53,7 @@ constexpr int kPitch = 80;        // bytes per LDS pixel row: 64 payload + 16 pa
 constexpr int kChunkBytes = 64;   // K payload per pixel per chunk
 constexpr int kPixels = 256;      // output pixels per workgroup
 constexpr int kPixelsWide = 512;  // ... of the float kernel on layers with enough pixels to fill the chip with such tiles
+constexpr int kPixelsHalf = 128;  // ... of the float kernel at stride 2, where LDS holds the footprint of 128 output pixels only
 constexpr int kThreads = 256;
 constexpr int kPitchSplit = 144;  // bytes per LDS pixel row of a float tensor split into 2 half planes: 2 x 64 + 16 pad
 constexpr int kSplitTaps = 3;     // taps of the weight chunk held in LDS at a time (split float path)
@@ -361,8 +362,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         const int64_t x_plane8 = (int64_t)p.h * p.w_in * 8;   // 16-byte units from one chunk of a sample to the next
         const int chunks = t.chunks, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
         const int cb_begin = ksplit * chunks_per_split, cb_end = min(chunks, cb_begin + chunks_per_split);
-        constexpr bool ONE_AHEAD = PX != kPixels;
-        uint4 wreg_a[W_IT], wreg_b[ONE_AHEAD ? 1 : W_IT], xreg[X_IT];
+        uint4 wreg_a[W_IT], wreg_b[W_IT], xreg[X_IT];
         auto w_load = [&](uint4 (&wreg)[W_IT], int cb, int g0) {
             const int gtaps = min(kSplitTaps, taps - g0);
 #pragma unroll
@@ -426,8 +426,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             }
         };
         // Stage = (chunk, tap group).  The weights of a stage are requested two stages ahead (two register sets
-        // used in turn; one stage ahead with one set in the wide tile, whose stages are twice as long and which has
-        // no registers to spare) and written to the LDS buffer the current stage does not read, after its multiplies; the
+        // used in turn) and written to the LDS buffer the current stage does not read, after its multiplies; the
         // footprint of the next chunk is requested at the first stage of the current one and written - to a second
         // footprint buffer when LDS has room for it (t.x_double), else after one more barrier - at its last stage.
         // One barrier per stage: a wave's LDS writes and address arithmetic overlap the other waves' multiplies.
@@ -447,7 +446,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         if (cb < cb_end) {
             w_load(wreg_a, cb, g0);
             x_load(cb);
-            if constexpr (!ONE_AHEAD) w_load(wreg_b, cb1, g1);
+            w_load(wreg_b, cb1, g1);
 #ifndef BAND_ABL_NOSTAGE
             x_commit(s_x[cb & 1], cb);
             w_commit(wreg_a, s_wb[0], g0);
@@ -458,8 +457,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         // after it and `far` is free: it receives the request for two stages on.
         auto stage = [&](uint4 (&next)[W_IT], uint4 (&far)[W_IT]) {
             const bool first = g0 == 0, last = cb1 != cb;
-            if constexpr (ONE_AHEAD) w_load(next, cb1, g1);
-            else w_load(far, cb2, g2);
+            w_load(far, cb2, g2);
             if (first && cb + 1 < cb_end) x_load(cb + 1);
 #ifndef BAND_ABL_NOCOMPUTE
             split_multiply(s_wb[sidx & 1], s_x[cb & 1], g0, min(kSplitTaps, taps - g0));
@@ -480,13 +478,9 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             sidx++;
         };
         while (cb < cb_end) {
-            if constexpr (ONE_AHEAD) {
-                stage(wreg_a, wreg_a);
-            } else {
-                stage(wreg_b, wreg_a);
-                if (cb >= cb_end) break;
-                stage(wreg_a, wreg_b);
-            }
+            stage(wreg_b, wreg_a);
+            if (cb >= cb_end) break;
+            stage(wreg_a, wreg_b);
         }
     }
     const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
@@ -802,14 +796,24 @@ Tile make_tile_of(const sg_conv2d_params& p, int px, int* out_max_taps) {
 
 // The float kernel takes 512 pixels per workgroup (every staged weight then feeds twice the multiplies, and the
 // weights are what its workgroups read most of) where such tiles are filled and still give every CU a workgroup.
+// At stride 2 the footprint of 128 output pixels fills LDS: such layers run with 128 pixel slots (one 16-pixel tile
+// per wave) instead of multiplying 128 idle slots along.
 Tile make_tile(const sg_conv2d_params& p, int* out_max_taps) {
-    if (p.dtype == SG_F32 && p.co >= 64) {
+    const bool wide_ok = p.dtype == SG_F32 && p.co >= 64 &&
+                         split_bytes((int64_t)p.n * p.h * p.w_in, p.ci) / 16 < (size_t)INT32_MAX;
+    const auto blocks = [&](const Tile& t) {
+        return (int64_t)t.tiles_a * t.tiles_b * t.tiles_img * p.num_phases * ((p.co + 63) / 64);
+    };
+    if (wide_ok) {
         const Tile t = make_tile_of(p, kPixelsWide, out_max_taps);
-        const bool small = split_bytes((int64_t)p.n * p.h * p.w_in, p.ci) / 16 < (size_t)INT32_MAX;
-        const int64_t blocks = (int64_t)t.tiles_a * t.tiles_b * t.tiles_img * p.num_phases * ((p.co + 63) / 64);
-        if (small && t.imgs * t.th * t.tw >= kPixelsWide * 3 / 4 && blocks >= 256) return t;
+        if (t.imgs * t.th * t.tw >= kPixelsWide * 3 / 4 && blocks(t) >= 256) return t;
     }
-    return make_tile_of(p, kPixels, out_max_taps);
+    const Tile t = make_tile_of(p, kPixels, out_max_taps);
+    if (wide_ok && p.in_step == 2 && t.imgs * t.th * t.tw <= kPixelsHalf && blocks(t) >= 256) {
+        const Tile h = make_tile_of(p, kPixelsHalf, out_max_taps);
+        if (h.imgs * h.th * h.tw == t.imgs * t.th * t.tw) return h;
+    }
+    return t;
 }
 
 template <class T>
@@ -832,7 +836,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     // 64 output channels per workgroup (every staged pixel then feeds four times the multiplies), unless that
     // leaves most of the 256 CUs without a workgroup even with the channel sum divided
     const int64_t tiles_px = tiles * p.num_phases;
-    const int m_tiles = (t.px > kPixels || (p.co > 16 && tiles_px * ((p.co + 63) / 64) * max_split >= 256)) ? 4 : 1;
+    const int m_tiles = (t.px != kPixels || (p.co > 16 && tiles_px * ((p.co + 63) / 64) * max_split >= 256)) ? 4 : 1;
     const int BM = 16 * m_tiles;
     size_t lds = ((size_t)t.imgs * t.lh * t.lw + (size_t)max_taps * BM) * PITCH;
     t.max_taps = max_taps;
@@ -858,7 +862,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     }
     // Wide epilogue: whole 8-pixel packets of a row must be addressable with aligned 16-byte accesses.
     t.vec_epi = t.split_k == 1 && p.out_step == 1 && p.num_phases == 1 && p.phase[0].oy0 == 0 && p.phase[0].ox0 == 0 &&
-                p.ow % 8 == 0 && t.tw % 8 == 0 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
+                t.px >= kPixels && p.ow % 8 == 0 && t.tw % 8 == 0 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
                 (!p.reduce_out || aligned16(p.reduce_x));
     if (t.vec_epi) lds = std::max(lds, (size_t)t.px * (BM + 4) * sizeof(float));
     t.amax = nullptr;
@@ -893,6 +897,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
     auto kernel = (m_tiles == 4) ? conv2d_mfma_kernel<T, 4> : conv2d_mfma_kernel<T, 1>;
     if constexpr (SPLIT) {
         if (t.px > kPixels) kernel = conv2d_mfma_kernel<T, 4, kPixelsWide>;
+        if (t.px < kPixels) kernel = conv2d_mfma_kernel<T, 4, kPixelsHalf>;
     }
     if (lds > 64 * 1024) {   // opt in to large dynamic LDS (idempotent, cheap)
         hipError_t e = allow_large_lds((const void*)kernel);

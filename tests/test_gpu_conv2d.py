@@ -115,6 +115,7 @@ WIDE_CASES = [  # name, n, ci, co, h, w, kind: float32 layers large enough for t
     ('f32_wide_ragged', 6, 40, 264, 50, 72, 'conv'),
     ('f32_up_33', 6, 32, 192, 32, 32, 'conv_transpose'),      # phases of 33 and 32 pixels: tiles of equal size
     ('f32_up_rect', 5, 64, 136, 35, 48, 'conv_transpose'),
+    ('f32_down', 6, 40, 264, 73, 80, 'conv_s2'),                # stride 2: 128 pixel slots per workgroup
 ]
 
 
@@ -133,6 +134,11 @@ def test_conv2d_float_large_layers(case):
         wt = torch.randn([co, ci, 3, 3], generator=g) / (ci * 9) ** 0.5
         conv = lambda t: F.conv2d(t, wt.double(), padding=1)
         plan = cp.plan_conv(3, 3, padding=1)
+        packed = plan.pack(wt.to(DEV))
+    elif kind == 'conv_s2':
+        wt = torch.randn([co, ci, 3, 3], generator=g) / (ci * 9) ** 0.5
+        conv = lambda t: F.conv2d(t, wt.double(), stride=2)
+        plan = cp.plan_conv(3, 3, stride=2, padding=0)
         packed = plan.pack(wt.to(DEV))
     else:
         wt = torch.randn([ci, co, 3, 3], generator=g) / (ci * 9) ** 0.5
