@@ -16,7 +16,8 @@ SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d
            'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad', 'sg_upfirdn2d_epilogue',
            'sg_epilogue_backward', 'sg_conv2d_reduce_rows', 'sg_conv2d_kernel', 'sg_conv2d_wgrad_kernel',
            'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask',
-           'sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes', 'sg_conv_up2_fir', 'sg_conv_up2_fir_supported')
+           'sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes', 'sg_conv_up2_fir', 'sg_conv_up2_fir_supported',
+           'sg_upfirdn2d_add', 'sg_upfirdn2d_add_supported')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -69,6 +70,10 @@ def lib():
             fn.restype = ctypes.c_int
         handle.sg_upfirdn2d_epilogue.argtypes = [ctypes.POINTER(Upfirdn2dParams), vp, vp]
         handle.sg_upfirdn2d_epilogue.restype = ctypes.c_int
+        handle.sg_upfirdn2d_add.argtypes = [ctypes.POINTER(Upfirdn2dParams), vp, vp]
+        handle.sg_upfirdn2d_add.restype = ctypes.c_int
+        handle.sg_upfirdn2d_add_supported.argtypes = [ctypes.POINTER(Upfirdn2dParams)]
+        handle.sg_upfirdn2d_add_supported.restype = ctypes.c_int
         for name in ('sg_conv2d', 'sg_conv2d_wgrad', 'sg_epilogue_backward', 'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask'):     # structs declared in the plugin modules
             getattr(handle, name).argtypes = [vp, vp]
             getattr(handle, name).restype = ctypes.c_int

@@ -363,7 +363,7 @@ int launch_down2_pad(const sg_upfirdn2d_params& p, hipStream_t stream) {
 // starts the rows 2r - 1, 2r (filter rows 1 and 0), with e = output row - pad_y0.  No rotation, 2 packed
 // multiply-adds per output.
 template <class T, int PADX>
-__global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, int lpr, int cblocks, int bands, int units) {
+__global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, const void* addend, int lpr, int cblocks, int bands, int units) {
     constexpr int kColsUp = 1024;                 // 16 output columns per lane
     const int lane = threadIdx.x & 63;
     const int wave_unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -378,6 +378,9 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
     const T* __restrict__ x1 = (const T*)p.x + (int64_t)n1 * p.in_stride_n + (int64_t)c1 * p.in_stride_c;
     T* __restrict__ y0 = (T*)p.y + (int64_t)n0 * p.out_stride_n + (int64_t)c0 * p.out_stride_c;
     T* __restrict__ y1 = (T*)p.y + (int64_t)n1 * p.out_stride_n + (int64_t)c1 * p.out_stride_c;
+    // optional addend with the output's strides: y = round(round(filtered) + addend), the arithmetic of a separate add
+    const T* __restrict__ a0 = addend ? (const T*)addend + (int64_t)n0 * p.out_stride_n + (int64_t)c0 * p.out_stride_c : nullptr;
+    const T* __restrict__ a1 = addend ? (const T*)addend + (int64_t)n1 * p.out_stride_n + (int64_t)c1 * p.out_stride_c : nullptr;
     const int ox0 = cb * kColsUp + (lane - sub * lpr) * 16, oy0 = bd * kBand;
     const int rows = live ? min(kBand, p.out_h - oy0) : 0;
     const bool col_ok = live && ox0 < p.out_w;
@@ -421,15 +424,27 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
         const int oy = e + p.pad_y0;
         if (oy < oy0 || oy >= oy0 + rows || !col_ok) return;
         const int64_t off = (int64_t)oy * p.out_stride_h + ox0;
+        auto plus = [&](const uint4& r, const T* a) __attribute__((always_inline)) {   // packed results + 8 addend elements
+            const uint4 q = *reinterpret_cast<const uint4*>(a);
+            const unsigned rw[4] = {r.x, r.y, r.z, r.w}, qw[4] = {q.x, q.y, q.z, q.w};
+            unsigned o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                o[j] = Pair<T>::pack(Pair<T>::lo(rw[j]) + Pair<T>::lo(qw[j]), Pair<T>::hi(rw[j]) + Pair<T>::hi(qw[j]));
+            return make_uint4(o[0], o[1], o[2], o[3]);
+        };
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            *reinterpret_cast<uint4*>(y0 + off + 8 * h) =
-                make_uint4(Pair<T>::pack(v[8 * h][0], v[8 * h + 1][0]), Pair<T>::pack(v[8 * h + 2][0], v[8 * h + 3][0]),
-                           Pair<T>::pack(v[8 * h + 4][0], v[8 * h + 5][0]), Pair<T>::pack(v[8 * h + 6][0], v[8 * h + 7][0]));
-            if (second)
-                *reinterpret_cast<uint4*>(y1 + off + 8 * h) =
-                    make_uint4(Pair<T>::pack(v[8 * h][1], v[8 * h + 1][1]), Pair<T>::pack(v[8 * h + 2][1], v[8 * h + 3][1]),
-                               Pair<T>::pack(v[8 * h + 4][1], v[8 * h + 5][1]), Pair<T>::pack(v[8 * h + 6][1], v[8 * h + 7][1]));
+            uint4 r0 = make_uint4(Pair<T>::pack(v[8 * h][0], v[8 * h + 1][0]), Pair<T>::pack(v[8 * h + 2][0], v[8 * h + 3][0]),
+                                  Pair<T>::pack(v[8 * h + 4][0], v[8 * h + 5][0]), Pair<T>::pack(v[8 * h + 6][0], v[8 * h + 7][0]));
+            if (a0) r0 = plus(r0, a0 + off + 8 * h);
+            *reinterpret_cast<uint4*>(y0 + off + 8 * h) = r0;
+            if (second) {
+                uint4 r1 = make_uint4(Pair<T>::pack(v[8 * h][1], v[8 * h + 1][1]), Pair<T>::pack(v[8 * h + 2][1], v[8 * h + 3][1]),
+                                      Pair<T>::pack(v[8 * h + 4][1], v[8 * h + 5][1]), Pair<T>::pack(v[8 * h + 6][1], v[8 * h + 7][1]));
+                if (a1) r1 = plus(r1, a1 + off + 8 * h);
+                *reinterpret_cast<uint4*>(y1 + off + 8 * h) = r1;
+            }
         }
     };
     auto consume = [&](int k, const Row& row) __attribute__((always_inline)) {
@@ -489,24 +504,24 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
 }
 
 template <class T, int PADX>
-int launch_up2(const sg_upfirdn2d_params& p, hipStream_t stream) {
+int launch_up2(const sg_upfirdn2d_params& p, const void* addend, hipStream_t stream) {
     const int cblocks = (p.out_w + 1023) / 1024, bands = (p.out_h + kBand - 1) / kBand;
     const int lpr = cblocks > 1 ? 64 : p.out_w / 16;
     const int64_t pairs = ((int64_t)p.in_n * p.in_c + 1) / 2;
     const int64_t units = pairs * cblocks * bands;
     SG_REQUIRE(units <= INT32_MAX / 2, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
     const int64_t waves = (units + 64 / lpr - 1) / (64 / lpr);
-    hipLaunchKernelGGL((up2_stream_kernel<T, PADX>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p, lpr, cblocks, bands, (int)units);
+    hipLaunchKernelGGL((up2_stream_kernel<T, PADX>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p, addend, lpr, cblocks, bands, (int)units);
     return check_launch("sg_upfirdn2d (up-sampling stream)");
 }
 
 template <class T>
-int launch_up2_pad(const sg_upfirdn2d_params& p, hipStream_t stream) {
+int launch_up2_pad(const sg_upfirdn2d_params& p, const void* addend, hipStream_t stream) {
     switch (p.pad_x0) {
-        case 0: return launch_up2<T, 0>(p, stream);
-        case 1: return launch_up2<T, 1>(p, stream);
-        case 2: return launch_up2<T, 2>(p, stream);
-        default: return launch_up2<T, 3>(p, stream);
+        case 0: return launch_up2<T, 0>(p, addend, stream);
+        case 1: return launch_up2<T, 1>(p, addend, stream);
+        case 2: return launch_up2<T, 2>(p, addend, stream);
+        default: return launch_up2<T, 3>(p, addend, stream);
     }
 }
 
@@ -599,9 +614,9 @@ bool up2_stream_eligible(const sg_upfirdn2d_params& p) {
     return aligned16(p.x) && aligned16(p.y);
 }
 
-int up2_stream_launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
-    if (p.dtype == SG_BF16) return launch_up2_pad<__hip_bfloat16>(p, stream);
-    return launch_up2_pad<__half>(p, stream);
+int up2_stream_launch(const sg_upfirdn2d_params& p, const void* addend, hipStream_t stream) {
+    if (p.dtype == SG_BF16) return launch_up2_pad<__hip_bfloat16>(p, addend, stream);
+    return launch_up2_pad<__half>(p, addend, stream);
 }
 
 int blur_stream_launch(const sg_upfirdn2d_params& p, const sg_epilogue* ep, hipStream_t stream) {

@@ -18,6 +18,7 @@ int down2_stream_launch(const sg_upfirdn2d_params& p, hipStream_t stream);
 
 // up = 2, down = 1 under the same conditions, output rows of whole pairs of packets (the adjoint of the above)
 bool up2_stream_eligible(const sg_upfirdn2d_params& p);
-int up2_stream_launch(const sg_upfirdn2d_params& p, hipStream_t stream);
+// `addend` (may be NULL): a tensor with y's dtype and strides that is added to the filtered result
+int up2_stream_launch(const sg_upfirdn2d_params& p, const void* addend, hipStream_t stream);
 
 }  // namespace sg

@@ -396,7 +396,7 @@ int launch(const sg_upfirdn2d_params& p, hipStream_t stream) {
         const int ux = p.up_x, uy = p.up_y, dx = p.down_x, dy = p.down_y;
         if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return launch_blur4<T>(p, stream);
         if (ux == 2 && uy == 2 && dx == 1 && dy == 1) {
-            if (up2_stream_eligible(p)) return up2_stream_launch(p, stream);
+            if (up2_stream_eligible(p)) return up2_stream_launch(p, nullptr, stream);
             return launch_tiled<T, 2, 2, 1, 1, 4, 4, 64, 16>(p, stream);
         }
         if (ux == 1 && uy == 1 && dx == 2 && dy == 2) {
@@ -451,6 +451,26 @@ extern "C" int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream) {
     SG_REQUIRE(p->x && p->f && p->y, SG_ERR_NULL_POINTER, "x, f and y must not be NULL");
     SG_DISPATCH_DTYPE(p->dtype, true, return launch<T>(*p, (hipStream_t)stream));
     return SG_OK;
+}
+
+extern "C" int sg_upfirdn2d_add_supported(const sg_upfirdn2d_params* p) {
+    return (p != nullptr && p->in_c > 0 && p->in_n > 0 && p->out_w >= 1 && p->out_h >= 1 && sg::up2_stream_eligible(*p)) ? 1 : 0;
+}
+
+extern "C" int sg_upfirdn2d_add(const sg_upfirdn2d_params* p, const void* addend, sg_stream_t stream) {
+    using namespace sg;
+    if (addend == nullptr) return sg_upfirdn2d(p, stream);
+    SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
+    SG_REQUIRE(p->in_w >= 0 && p->in_h >= 0 && p->in_c >= 0 && p->in_n >= 0, SG_ERR_INVALID_ARGUMENT, "negative input size");
+    SG_REQUIRE(p->out_w >= 1 && p->out_h >= 1, SG_ERR_INVALID_ARGUMENT, "output must be at least 1x1");
+    SG_REQUIRE((int64_t)p->in_w * p->in_h * p->in_c * p->in_n <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "x is too large");
+    SG_REQUIRE((int64_t)p->out_w * p->out_h * p->in_c * p->in_n <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "output is too large");
+    if (p->in_c == 0 || p->in_n == 0) return SG_OK;
+    SG_REQUIRE(p->x && p->f && p->y, SG_ERR_NULL_POINTER, "x, f and y must not be NULL");
+    SG_REQUIRE(sg_upfirdn2d_add_supported(p) && aligned16(addend), SG_ERR_UNSUPPORTED,
+               "upfirdn2d with addend: only the up-sampling stream geometry (16-bit, up 2, down 1, filter up to 4x4, rows of whole "
+               "aligned packets, output at least 64 wide with an even number of rows)");
+    return up2_stream_launch(*p, addend, (hipStream_t)stream);
 }
 
 extern "C" int sg_upfirdn2d_epilogue(const sg_upfirdn2d_params* p, const sg_epilogue* ep, sg_stream_t stream) {

@@ -244,8 +244,22 @@ class _FusedConv(torch.autograd.Function):
                 dbias.to(bias.dtype) if dbias is not None else None, None, None)
 
 
+def _down_padding(f, k, padding, down=2):
+    fw, fh = _get_filter_size(f)
+    pad = int(padding)
+    return [pad + (fw - down + 1) // 2, pad + (fw - down) // 2, pad + (fh - down + 1) // 2, pad + (fh - down) // 2]
+
+
+def branch_down(x, f, padding=0):
+    """(x, x filtered and down-sampled by 2) for the input of a down-sampling 1x1 layer that is consumed a second time
+    (a residual block's `skip` beside its `conv0`): pass the first result on to the other consumer and the second to
+    `conv_layer(..., down=2, prefiltered=True)`.  The two gradients of x then meet inside the filter's backward kernel
+    instead of in a sum of their own."""
+    return upfirdn2d.branch(x, f, down=2, padding=_down_padding(f, 1, padding))
+
+
 def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=None, dcoefs=None, noise=None,
-               noise_strength=None, bias=None, act='linear', alpha=None, gain=None, clamp=None):
+               noise_strength=None, bias=None, act='linear', alpha=None, gain=None, clamp=None, prefiltered=False):
     """clamp(act(conv2d_resample(x * styles, w, f, up, down, padding) * dcoefs + noise * noise_strength + bias) * gain).
 
     x [N, I, H, W]; w [O, I, k, k] in x's dtype; styles [N, I] / dcoefs [N, O] float32 or None; noise a
@@ -281,7 +295,8 @@ def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=N
         if not flip_weight:
             w = _flipped(w)
         if k == 1:
-            x = upfirdn2d.upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1])
+            if not prefiltered:     # (else x is the second result of branch_down)
+                x = upfirdn2d.upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1])
             cfg = ('same', 1, 1, 0, tuple(x.shape[2:]), act, alpha, gain, clamp, None, 0)
         else:
             out_hw = ((x.shape[2] + py0 + py1 - fh + 1 - k) // down + 1, (x.shape[3] + px0 + px1 - fw + 1 - k) // down + 1)

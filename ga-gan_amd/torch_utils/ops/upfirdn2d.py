@@ -103,6 +103,55 @@ class _Upfirdn2d(torch.autograd.Function):
         return dx, None, None
 
 
+class _Branch(torch.autograd.Function):
+    """(x, upfirdn2d(x, f, cfg)) for a tensor that has a second consumer beside the filter - the input of a residual
+    discriminator block feeds `skip` (a down-sampling filter in front of its 1x1 convolution) and `conv0`
+    (training/networks.py:792-808).  The gradient of such a tensor is the sum of what the two consumers return;
+    autograd adds them in a pass of its own (read both, write one).  Here the backward hands the gradient that
+    arrived for x to the kernel that applies the filter's adjoint, which adds it while it stores (`sg_upfirdn2d_add`).
+    cfg as in `_Upfirdn2d`; two-dimensional filters only."""
+
+    @staticmethod
+    def forward(ctx, x, f, cfg):
+        upx, upy, downx, downy, px0, px1, py0, py1, flip, gain = cfg
+        assert isinstance(f, torch.Tensor) and f.ndim == 2
+        y = _plugin.upfirdn2d(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain)
+        ctx.save_for_backward(f)
+        ctx.cfg = cfg
+        ctx.x_shape = x.shape
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, gx, gy):
+        f, = ctx.saved_tensors
+        if gy is None or not ctx.needs_input_grad[0]:
+            return (gx if ctx.needs_input_grad[0] else None), None, None
+        upx, upy, downx, downy, px0, px1, py0, py1, flip, gain = ctx.cfg
+        _, _, ih, iw = ctx.x_shape
+        _, _, oh, ow = gy.shape
+        fw, fh = _get_filter_size(f)
+        adj = (downx, downy, upx, upy,
+               fw - px0 - 1, iw * upx - ow * downx + px0 - upx + 1,
+               fh - py0 - 1, ih * upy - oh * downy + py0 - upy + 1,
+               not flip, gain)
+        if gx is not None and not torch.is_grad_enabled():   # (a higher-order graph keeps the two differentiable steps)
+            both = _plugin.upfirdn2d_add(gy.contiguous(), f, *adj, addend=gx.contiguous())
+            if both is not None:
+                return both, None, None
+        d = _Upfirdn2d.apply(gy, f, adj)
+        return (d if gx is None else gx + d), None, None
+
+
+def branch(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """(x, upfirdn2d(x, f, up, down, padding, flip_filter, gain)): use the first result wherever x is consumed again, so
+    that the gradients of both uses meet inside the filter's backward instead of in a separate sum."""
+    misc.require_gpu(x, 'upfirdn2d')
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    return _Branch.apply(x, f, (upx, upy, downx, downy, px0, px1, py0, py1, bool(flip_filter), float(gain)))
+
+
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda'):
     """Pad, up-sample (zero insertion), FIR-filter and down-sample x[N, C, H, W].
 

@@ -468,17 +468,27 @@ class Conv2dLayer(torch.nn.Module):
             else:
                 self.bias = None
 
-    def forward(self, x, gain=1):
+    def forward(self, x, gain=1, also_input=False):
+        """`also_input=True` returns (x, y) for a caller that feeds x to a second layer as well: it must use the returned
+        x there (a 16-bit down-sampling 1x1 layer then receives both gradients of x in its filter's backward kernel)."""
         w = _prepared(self, self.weight, self.weight_gain, x.dtype, 'w')
         b = _prepared(self, self.bias, 1, x.dtype, 'b') if self.bias is not None else None
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         if FUSE_LAYERS and self.activation in ('linear', 'lrelu') and fused_layer.supported(x, w, self.up, self.down):
-            return fused_layer.conv_layer(x, w, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
-                                          flip_weight=(self.up == 1), bias=b, act=self.activation,
-                                          gain=self.act_gain * gain, clamp=act_clamp)
-        x = conv2d_resample.conv2d_resample(x=x, w=w, f=self.resample_filter, up=self.up, down=self.down,
+            if also_input and self.down == 2 and w.shape[2] == 1 and x.dtype != torch.float32 and x.requires_grad \
+                    and x.is_contiguous() and self.resample_filter.ndim == 2:
+                x, xd = fused_layer.branch_down(x, self.resample_filter, self.padding)
+                return x, fused_layer.conv_layer(xd, w, f=self.resample_filter, up=1, down=2, padding=self.padding, bias=b,
+                                                 act=self.activation, gain=self.act_gain * gain, clamp=act_clamp,
+                                                 prefiltered=True)
+            y = fused_layer.conv_layer(x, w, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+                                       flip_weight=(self.up == 1), bias=b, act=self.activation,
+                                       gain=self.act_gain * gain, clamp=act_clamp)
+            return (x, y) if also_input else y
+        y = conv2d_resample.conv2d_resample(x=x, w=w, f=self.resample_filter, up=self.up, down=self.down,
                                             padding=self.padding, flip_weight=(self.up == 1))
-        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
+        y = bias_act.bias_act(y, b, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
+        return (x, y) if also_input else y
 
 
 class MappingNetwork(torch.nn.Module):
@@ -802,7 +812,7 @@ class DiscriminatorBlock(torch.nn.Module):
             x = x + y if x is not None else y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
+            x, y = self.skip(x, gain=np.sqrt(0.5), also_input=True)
             x = self.conv0(x)
             x = self.conv1(x, gain=np.sqrt(0.5))
             x = y.add_(x)

@@ -74,6 +74,17 @@ typedef struct sg_upfirdn2d_params {
 int sg_upfirdn2d_out_size(int in_size, int up, int pad0, int pad1, int f_size, int down);
 int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream);
 
+/* y = round(upfirdn2d(x)) + addend, rounded once more: the filter followed by a separate element-wise sum, in one pass.
+ * `addend` has y's dtype, shape and strides (it may be y itself).  This is the backward of a tensor that feeds both a
+ * down-sampling filter and a second consumer (the input of a residual discriminator block, training/networks.py:
+ * 792-808 - `self.skip(x)` beside `self.conv0(x)`): the adjoint of the filter (upfirdn2d.py:290-304) and the sum of
+ * the two gradients that autograd would add in a pass of its own.  Only the up-sampling stream geometry is covered
+ * (16-bit, up 2, down 1, filter up to 4x4, contiguous rows of whole aligned packets, output at least 64 pixels wide,
+ * even number of output rows): ask sg_upfirdn2d_add_supported() first; anything else returns SG_ERR_UNSUPPORTED.
+ * addend == NULL is sg_upfirdn2d. */
+int sg_upfirdn2d_add(const sg_upfirdn2d_params* p, const void* addend, sg_stream_t stream);
+int sg_upfirdn2d_add_supported(const sg_upfirdn2d_params* p);
+
 /* Layer epilogue applied to a value v produced for sample n, channel c, pixel (oy, ox):
  *   clamp(act(v * scale[n,c] + noise[n,oy,ox] * *noise_gain + bias[c]) * gain)
  * scale [n, channels], noise [.., oh, ow] (noise_stride_n elements between samples, 0 = shared) and
