@@ -9,6 +9,7 @@ import torch
 
 from ... import bias_act_plugin as _plugin
 from .. import misc
+from . import conv2d_gradfix
 
 
 def _spec(func, def_alpha, def_gain, cuda_idx, ref, has_2nd_grad):
@@ -78,7 +79,9 @@ class _BiasAct(torch.autograd.Function):
             dx = dy
             if act != 'linear' or gain != 1 or clamp >= 0:
                 dx = _BiasActGrad.apply(dy, x, b, y, ctx.cfg)
-        if ctx.needs_input_grad[1]:
+        # (inside conv2d_gradfix.no_weight_gradients() - the first-order passes of the two regularisers, which ask for the
+        # gradient of an activation only - the bias gradient is a reduction over the whole tensor that nobody reads)
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
             db = _sum_except(dx, dim)
         return dx, db, None
 

@@ -1,6 +1,8 @@
 """a * b + c with broadcasting and cheap gradients (reference: torch_utils/ops/fma.py)."""
 import torch
 
+from . import conv2d_gradfix
+
 
 def fma(a, b, c):
     return _Fma.apply(a, b, c)
@@ -30,5 +32,7 @@ class _Fma(torch.autograd.Function):
         a, b = ctx.saved_tensors
         da = _reduce_to(dout * b, a.shape) if ctx.needs_input_grad[0] else None
         db = _reduce_to(dout * a, b.shape) if ctx.needs_input_grad[1] else None
-        dc = _reduce_to(dout, ctx.c_shape) if ctx.needs_input_grad[2] else None
+        # c is the noise term of a synthesis layer (noise buffer x learned strength): like a weight gradient, its gradient
+        # is not wanted inside conv2d_gradfix.no_weight_gradients()
+        dc = _reduce_to(dout, ctx.c_shape) if ctx.needs_input_grad[2] and not conv2d_gradfix.weight_gradients_disabled else None
         return da, db, dc
