@@ -20,7 +20,7 @@ from ... import layer_plugin as _layer
 from ... import upfirdn2d_plugin as _fir
 from . import bias_act
 from . import conv2d_gradfix
-from . import fma
+from . import planes
 from . import upfirdn2d
 from .. import memo
 from .conv2d_resample import _align_extra
@@ -105,7 +105,7 @@ def _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg):
     mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
     n = x.shape[0]
     if styles is not None:
-        x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+        x = planes.scale_planes(x, styles)
     if mode == 'same':
         c = conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding, output_size=out_hw)
     else:
@@ -114,11 +114,9 @@ def _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg):
     nz = None
     if noise is not None:
         nz = (noise * noise_strength).to(x.dtype) if noise_strength is not None else noise.to(x.dtype)
-    if dcoefs is not None and nz is not None:
-        c = fma.fma(c, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), nz)
-    elif dcoefs is not None:
-        c = c * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
-    elif nz is not None:
+    if dcoefs is not None:
+        c = planes.scale_planes(c, dcoefs)
+    if nz is not None:
         c = c + nz
     return bias_act.bias_act(c, bias, act=act, alpha=alpha, gain=gain, clamp=clamp if clamp >= 0 else None)
 

@@ -85,6 +85,19 @@ int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream);
 int sg_upfirdn2d_add(const sg_upfirdn2d_params* p, const void* addend, sg_stream_t stream);
 int sg_upfirdn2d_add_supported(const sg_upfirdn2d_params* p);
 
+/* Per-plane scale and its gradient, for dense tensors viewed as [planes][pixels] (plane = one channel of one sample):
+ *   sg_scale_planes:  y[p][i] = x[p][i] * s[p]                         s float32 [planes]
+ *   sg_dot_planes:    part[p][k] = sum over segment k of a[p][i] * b[p][i]   part float32 [planes][sg_planes_segments()]
+ * (the caller adds the segments of a plane).  They stand for the broadcast multiplies of the reference's
+ * modulated_conv2d - `x * styles.reshape(batch, -1, 1, 1)` and `x * dcoefs.reshape(batch, -1, 1, 1)`
+ * (training/networks.py:642, :648-650) - and for the multiply-and-reduce that autograd derives from them; each is the
+ * derivative of the other, so gradients of any order stay within the pair.  The scale stays float32 (the reference
+ * rounds it to the tensor's dtype first).  pixels must be a multiple of 16 bytes' worth of elements, tensors 16-byte
+ * aligned; SG_ERR_UNSUPPORTED otherwise. */
+int sg_planes_segments(int dtype, int64_t pixels);
+int sg_scale_planes(const void* x, const float* s, void* y, int dtype, int64_t planes, int64_t pixels, sg_stream_t stream);
+int sg_dot_planes(const void* a, const void* b, float* part, int dtype, int64_t planes, int64_t pixels, sg_stream_t stream);
+
 /* Layer epilogue applied to a value v produced for sample n, channel c, pixel (oy, ox):
  *   clamp(act(v * scale[n,c] + noise[n,oy,ox] * *noise_gain + bias[c]) * gain)
  * scale [n, channels], noise [.., oh, ow] (noise_stride_n elements between samples, 0 = shared) and
