@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SG_OPS_LIBRARY') or os.path.join(_HERE, 'libsgops.so')   # override: kernel experiments
 
-SYMBOLS = ('sg_version', 'sg_last_error', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
+SYMBOLS = ('sg_version', 'sg_last_error', 'sg_init', 'sg_upfirdn2d_out_size', 'sg_upfirdn2d', 'sg_bias_act',
            'sg_mbstd_forward', 'sg_mbstd_backward', 'sg_conv2d', 'sg_conv2d_wgrad', 'sg_upfirdn2d_epilogue',
            'sg_epilogue_backward', 'sg_conv2d_reduce_rows', 'sg_conv2d_kernel', 'sg_conv2d_wgrad_kernel',
            'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask',
@@ -62,6 +62,7 @@ def lib():
             raise ImportError(f'{LIB_PATH} does not export {missing}: rebuild it')
         handle.sg_last_error.restype = ctypes.c_char_p
         handle.sg_version.restype = ctypes.c_int
+        handle.sg_init.restype = ctypes.c_int
         handle.sg_upfirdn2d_out_size.argtypes = [ctypes.c_int] * 6
         for name, struct in (('sg_upfirdn2d', Upfirdn2dParams), ('sg_bias_act', BiasActParams),
                              ('sg_mbstd_forward', MbstdParams), ('sg_mbstd_backward', MbstdParams)):

@@ -1236,6 +1236,12 @@ __global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__
 }  // namespace
 }  // namespace sg
 
+extern "C" int sg_init(void) {
+    // Everything the entry points would otherwise look up on their first call on a device and that is not a stream
+    // operation: the address of the scratch array (hipGetSymbolAddress must not run inside a stream capture).
+    return sg::scratch_address() != nullptr ? SG_OK : SG_ERR_UNSUPPORTED;
+}
+
 extern "C" int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t stream) {
     using namespace sg;
     SG_REQUIRE(p != nullptr, SG_ERR_NULL_POINTER, "params is NULL");
@@ -1256,8 +1262,14 @@ extern "C" int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, s
                "with a workspace", (long long)partials, p->n, rows, p->co, (long long)kScratchFloats);
     float* ws = scratch_address();
     if (ws == nullptr) return SG_ERR_UNSUPPORTED;
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)partials * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return fail((int)e, "conv2d_reduced: clearing the scratch array failed: %s", hipGetErrorString(e));
+    // Cleared by a kernel, not hipMemsetAsync: a memset node recorded into a HIP graph was seen to act on the first
+    // replay only, and the kernels that add into the array with atomics need it zero on every replay.
+    {
+        const size_t words = (size_t)partials;
+        const unsigned zblocks = (unsigned)std::min<size_t>((words + 255) / 256, 4096);
+        hipLaunchKernelGGL(zero_words_kernel, dim3(zblocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)ws, words);
+        if (int rc = check_launch("sg_conv2d_reduced (zero)")) return rc;
+    }
     sg_conv2d_params q = *p;
     q.reduce_out = ws;
     const int rc = sg_conv2d(&q, stream);

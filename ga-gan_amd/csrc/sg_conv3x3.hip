@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 namespace sg {
 namespace {
@@ -75,15 +76,58 @@ template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) 
            ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
 }
 
+// Two 16-bit elements in a dword <-> two floats (one conversion instruction for the pair).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <class T> struct Pair;
+template <> struct Pair<__hip_bfloat16> {
+    static __device__ __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        const bf16x2_t v = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
+template <> struct Pair<__half> {
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        const f16x2_t v = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
+
+// Buffer addressing: a resource descriptor bounds every access to `bytes` from its base; a byte offset at or beyond the
+// bound reads zeros.  A packet outside the image (or a channel beyond the last) therefore costs no branch and no
+// select in the loop: its offset is set to kOutside once, or the bound is drawn in front of it.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutside = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 load16(rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // WAVES = 4: the tile above.  WAVES = 8 (layers with more than 64 output channels): 128 output channels per
 // workgroup - waves 4..7 multiply the same staged pixels with the second 64 channels, so every staged input byte
-// feeds twice the multiplies; one such workgroup per CU, two waves per SIMD.
-template <class T, int STEP, int WAVES = 4>
+// feeds twice the multiplies; one such workgroup per CU, two waves per SIMD.  MOD: the input is modulated
+// (in_scale) while it is staged.
+//
+// Everything the staging needs per chunk is decided before the K loop: which (footprint row, packet) items a lane
+// moves and where they lie relative to the chunk's first channel (voff, kOutside for packets outside the image),
+// and where their eight pixels go in the LDS image.  A chunk then costs a handful of scalar instructions (the
+// descriptors move on by one chunk of channels), one load instruction per packet and, per pair of elements, two
+// multiplies and one conversion (or one byte permute without modulation).
+template <class T, int STEP, int WAVES, bool MOD>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS_PER_CU) conv3x3_kernel(Conv3x3Args g) {
     using G = Geo<STEP>;
     constexpr int NV = G::NV, LWP = G::LWP;
     constexpr int THREADS = 64 * WAVES, BMT = BM * (WAVES / 4);   // lanes and output channels per workgroup
     constexpr int SLOTS = THREADS / 16, STEPS = (G::ITEMS + SLOTS - 1) / SLOTS;   // staging: item slots, items per lane
+    constexpr bool LAST_PARTIAL = (G::ITEMS % SLOTS) != 0;        // the last item exists for the first slots only
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_in = smem;
     unsigned char* s_w = smem + G::kInBytes;
@@ -103,66 +147,82 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
     const int m0 = (unit / g.n) * BMT;
     const int a0 = ta * TH, b0 = tb * TW;
     const int plane = g.h * g.wid;
-    const T* __restrict__ x = (const T*)g.x + (unsigned)(n * g.ci * plane);   // fewer than 2^31 elements per tensor
-    const T* __restrict__ w = (const T*)g.w;
+    const T* __restrict__ xs = (const T*)g.x + (unsigned)(n * g.ci * plane);   // fewer than 2^31 elements per tensor
+    const unsigned plane_bytes = (unsigned)plane * 2u;
 
-    // ---- input fetch: lane = (channel pair cg = tid & 15, item slot tid >> 4); item = (footprint row, packet) ------
+    // ---- staging plan: lane = (channel pair cg = tid & 15, item slot tid >> 4); item = (footprint row, packet) -----
     const int cg = tid & 15, slot0 = tid >> 4;
-    const int px_first = b0 * STEP + g.px_shift;                    // first pixel column of the staged packets
-    const int iy_first = a0 * STEP + g.dy0;
-    uint4 va[STEPS], vb[STEPS], vw[9];
-    float s0 = 1.f, s1 = 1.f;
-
-    auto fetch = [&](int c0) {
-        const int c = c0 + 2 * cg;
-        const bool c_ok = c < g.ci, two = c + 1 < g.ci;
-        const T* src0 = x + (unsigned)(c * plane);
+    unsigned voff[STEPS];       // byte offset of the item's packet of channel 2 cg from the chunk's first channel
+    {
+        const int px_first = b0 * STEP + g.px_shift;                // first pixel column of the staged packets
+        const int iy_first = a0 * STEP + g.dy0;
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
             const int item = slot0 + SLOTS * q;
             const int ry = item / NV, v = item - ry * NV;
             const int iy = iy_first + ry, px0 = px_first + v * 8;
-            va[q] = make_uint4(0, 0, 0, 0);
-            vb[q] = make_uint4(0, 0, 0, 0);
-            if (c_ok && item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
-                const T* src = src0 + iy * g.wid + px0;
-                va[q] = *reinterpret_cast<const uint4*>(src);
-                if (two) vb[q] = *reinterpret_cast<const uint4*>(src + plane);
-            }
+            const bool ok = item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
+            voff[q] = ok ? (unsigned)(2 * cg * plane + iy * g.wid + px0) * 2u : kOutside;
         }
-        if (g.in_scale) {
-            s0 = (c < g.ci) ? g.in_scale[n * g.ci + c] : 0.f;
-            s1 = (c + 1 < g.ci) ? g.in_scale[n * g.ci + c + 1] : 0.f;
-        }
-        // weights [tap][co][ci]: packet e = tid + THREADS q is tap q, output channel tid >> 2, 16-byte slot tid & 3
-        const int o = m0 + (tid >> 2), cw = c0 + (tid & 3) * 8;
-        const bool w_ok = o < g.co && cw < g.ci;
+    }
+    const bool last_item = !LAST_PARTIAL || slot0 + SLOTS * (STEPS - 1) < G::ITEMS;
+    // LDS: item q lands in image rows (slot0 + SLOTS q) * 8 + j; the swizzle of such a row is that of j
+    int st_addr[4];             // byte address of the dword of pixel j = 2 jp (+ 64 for j = 2 jp + 1), item q = 0
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            vw[q] = make_uint4(0, 0, 0, 0);
-            if (w_ok) vw[q] = *reinterpret_cast<const uint4*>(w + (unsigned)((q * g.co + o) * g.ci + cw));
+    for (int jp = 0; jp < 4; jp++) st_addr[jp] = slot0 * 8 * kRow + swz(2 * jp, cg * 4);
+    // weights [tap][co][ci]: a lane moves, per tap, the 16-byte slot tid & 3 of output channel tid >> 2
+    const int w_o = m0 + (tid >> 2), w_c = (tid & 3) * 8;
+    const unsigned w_voff = (w_o < g.co) ? (unsigned)(w_o * g.ci + w_c) * 2u : kOutside;
+    const unsigned w_tap = (unsigned)(g.co * g.ci) * 2u;
+    const int w_st = swz(tid >> 2, (tid & 3) * 16);                 // + tap * BMT * kRow (BMT is a multiple of 8)
+    const T* __restrict__ w = (const T*)g.w;
+
+    uint4 va[STEPS], vb[STEPS], vw[9];
+    float s0 = 1.f, s1 = 1.f;
+
+    auto fetch = [&](int c0) {
+        const int left = min(KCH, g.ci - c0);                       // channels of this chunk
+        const rsrc_t rx = make_rsrc(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
+#pragma unroll
+        for (int q = 0; q < STEPS; q++) {
+            va[q] = load16(rx, voff[q], 0);
+            vb[q] = load16(rx, voff[q], plane_bytes);               // channel 2 cg + 1 (ci is a multiple of 8)
         }
+        if constexpr (MOD) {
+            const rsrc_t rs = make_rsrc(g.in_scale + (size_t)n * g.ci + c0, (unsigned)left * 4u);
+            // (two dword loads: hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to a single dword load)
+            s0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 0, 0));   // zero beyond the last channel
+            s1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 4, 0));
+        }
+        const rsrc_t rw = make_rsrc(w + c0, 9u * w_tap);
+        const unsigned wv = (w_c < left) ? w_voff : kOutside;       // the lane's slot of 8 channels lies in the chunk or not
+#pragma unroll
+        for (int q = 0; q < 9; q++) vw[q] = load16(rw, wv, (unsigned)q * w_tap);
     };
 
     auto commit = [&]() {
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
-            const int item = slot0 + SLOTS * q;
-            if (item >= G::ITEMS) continue;
+            if (LAST_PARTIAL && q == STEPS - 1 && !last_item) continue;
             const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
             const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
-            const int r0 = item * 8;   // image row (ry * NV + v) * 8 + j: a multiple of 8, the swizzle of r0 + j is that of j
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
-                unsigned out;
-                if (g.in_scale) out = pack16<T>(lo16<T>(ea) * s0, lo16<T>(eb) * s1);
-                else out = (ea & 0xffffu) | (eb << 16);
-                *reinterpret_cast<unsigned*>(s_in + swz(r0 + j, cg * 4)) = out;
+            for (int jp = 0; jp < 4; jp++) {
+                unsigned e0, e1;   // pixels 2 jp and 2 jp + 1: (channel 2 cg, channel 2 cg + 1)
+                if constexpr (MOD) {
+                    e0 = Pair<T>::pack(Pair<T>::lo(wa[jp]) * s0, Pair<T>::lo(wb[jp]) * s1);
+                    e1 = Pair<T>::pack(Pair<T>::hi(wa[jp]) * s0, Pair<T>::hi(wb[jp]) * s1);
+                } else {
+                    e0 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x05040100u);
+                    e1 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x07060302u);
+                }
+                unsigned char* dst = s_in + st_addr[jp] + q * (SLOTS * 8 * kRow);
+                *reinterpret_cast<unsigned*>(dst) = e0;
+                *reinterpret_cast<unsigned*>(dst + kRow) = e1;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 9; q++) *reinterpret_cast<uint4*>(s_w + swz(q * BMT + (tid >> 2), (tid & 3) * 16)) = vw[q];
+        for (int q = 0; q < 9; q++) *reinterpret_cast<uint4*>(s_w + w_st + q * (BMT * kRow)) = vw[q];
     };
 
     // ---- multiply-phase addressing ----------------------------------------------------------------------
@@ -518,6 +578,7 @@ bool conv3x3_eligible(const sg_conv2d_params& p) {
     if (ph.nky != 3 || ph.nkx != 3 || ph.oy0 != 0 || ph.ox0 != 0 || ph.w_offset != 0) return false;
     if (p.ow < TW || p.oh < 5) return false;                      // smaller outputs would leave most of the 8 x 32 tile empty
     if (p.w_in % 8 != 0 || p.ow % 4 != 0 || p.ci % 8 != 0) return false;
+    if ((int64_t)p.ci * p.h * p.w_in >= (int64_t)1 << 30) return false;   // a sample's bytes bound the buffer offsets (< 2^31)
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
     const auto aligned8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
     if (!aligned8(p.y) || !aligned8(p.reduce_x)) return false;   // reduce_x, not reduce_out: callers size reduce_out from this answer
@@ -571,7 +632,7 @@ static int launch_resident_for(const Conv3x3Args& g, int64_t units, int ci, int 
     return narrow ? launch_resident<T, 2, 2>(g, units, stream) : launch_resident<T, 2, 4>(g, units, stream);
 }
 
-template <class T, int STEP, int WAVES = 4>
+template <class T, int STEP, int WAVES, bool MOD>
 static int launch_step(Conv3x3Args g, hipStream_t stream) {
     constexpr int BMT = BM * (WAVES / 4);
     constexpr size_t lds = Geo<STEP>::kInBytes + kWBytes * (WAVES / 4);
@@ -579,7 +640,7 @@ static int launch_step(Conv3x3Args g, hipStream_t stream) {
     const int64_t units = (int64_t)g.tiles_a * g.tiles_b * g.n * ((g.co + BMT - 1) / BMT);
     SG_REQUIRE(units <= INT32_MAX - 8, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     g.units = (int)units;
-    auto kernel = conv3x3_kernel<T, STEP, WAVES>;
+    auto kernel = conv3x3_kernel<T, STEP, WAVES, MOD>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 7) / 8 * 8)), dim3(64 * WAVES), lds, stream, g);
@@ -587,10 +648,16 @@ static int launch_step(Conv3x3Args g, hipStream_t stream) {
 }
 
 // Layers with more than 64 output channels take the 8-wave form (128 channels per workgroup).
+template <class T, bool MOD>
+static int launch_wide_or_not_mod(const Conv3x3Args& g, int step, hipStream_t stream) {
+    static const bool force4 = getenv("SG_CONV3X3_WAVES4") != nullptr;   // EXPERIMENT
+    if (force4) return step == 1 ? launch_step<T, 1, 4, MOD>(g, stream) : launch_step<T, 2, 4, MOD>(g, stream);
+    if (step == 1) return (g.co > BM) ? launch_step<T, 1, 8, MOD>(g, stream) : launch_step<T, 1, 4, MOD>(g, stream);
+    return (g.co > BM) ? launch_step<T, 2, 8, MOD>(g, stream) : launch_step<T, 2, 4, MOD>(g, stream);
+}
 template <class T>
 static int launch_wide_or_not(const Conv3x3Args& g, int step, hipStream_t stream) {
-    if (step == 1) return (g.co > BM) ? launch_step<T, 1, 8>(g, stream) : launch_step<T, 1, 4>(g, stream);
-    return (g.co > BM) ? launch_step<T, 2, 8>(g, stream) : launch_step<T, 2, 4>(g, stream);
+    return g.in_scale ? launch_wide_or_not_mod<T, true>(g, step, stream) : launch_wide_or_not_mod<T, false>(g, step, stream);
 }
 
 int conv3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {

@@ -39,6 +39,12 @@ int sg_version(void);
 /* Message for the last non-zero return on the calling thread ("" if none). */
 const char* sg_last_error(void);
 
+/* Per-device set-up for the current device: resolves what the entry points otherwise look up on their first call
+ * on a device (the device address of sg_conv2d_reduced's array).  Optional, idempotent, cheap; call it once per
+ * device BEFORE recording calls into a HIP graph, because those look-ups are not stream operations and must not
+ * run inside a stream capture.  No counterpart in the reference (its plugins keep no per-device state). */
+int sg_init(void);
+
 /* ---------------------------------------------------------------------------
  * upfirdn2d: per (sample, channel) plane  zero-stuff by `up`, pad (negative =
  * crop), correlate with the flipped FIR filter (not flipped when `flip` != 0),
@@ -285,7 +291,9 @@ int sg_conv2d_reduce_rows(const sg_conv2d_params* p);
  * p->reduce_out must be NULL.  The call allocates and frees nothing; it is rejected with SG_ERR_UNSUPPORTED when
  * n * sg_conv2d_reduce_rows(p) * co exceeds the array, and with SG_ERR_INVALID_ARGUMENT when a float32 call comes
  * without p->workspace (sg_conv2d_workspace_bytes(p) bytes: the scratch of the float32 kernels is the caller's here).  Every call on a device shares that device's array: calls
- * whose execution may overlap on one device (different streams) race; calls on one stream are safe. */
+ * whose execution may overlap on one device (different streams) race; calls on one stream are safe.  The array is
+ * cleared by a kernel of the call itself, so a recorded call clears it on every replay of its graph; call sg_init()
+ * (or make one eager call) on the device before recording, so that the array's address is already known. */
 #define SG_CONV2D_REDUCED_MAX_PARTIALS (1 << 20)
 int sg_conv2d_reduced(const sg_conv2d_params* p, float* reduce_sum, sg_stream_t stream);
 

@@ -63,3 +63,37 @@ def test_conv2d_reduced_rejects_oversize_and_bad_arguments():
     p.dtype, p.n, p.h, p.w_in, p.oh, p.ow = 0, 1, 16, 16, 16, 16     # float32 without a workspace: refused, not allocated for
     assert fn(ctypes.byref(p), _lib.ptr(x), None) == -1
     assert b'allocates nothing' in _lib.lib().sg_last_error()
+
+
+def test_conv2d_reduced_replays_from_a_graph():
+    """Recorded into a HIP graph (where hipMalloc fails and a memset node would act once), the call must clear its
+    array on every replay: the geometry whose kernel adds into the array with atomics, replayed three times on new
+    inputs, against sg_conv2d with a workspace each time."""
+    from ga_gan_amd import _lib, conv2d_plugin as cp
+    assert _lib.lib().sg_init() == 0          # resolves the array's address: not allowed inside a capture
+    n, ci, co, h, w = 5, 64, 32, 4, 4
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn([n, ci, h, w], device=DEV, generator=g).to(torch.bfloat16)
+    wt = (torch.randn([co, ci, 3, 3], device=DEV, generator=g) / (ci * 9) ** 0.5).to(torch.bfloat16)
+    rx = torch.randn([n, co, h, w], device=DEV, generator=g).to(torch.bfloat16)
+    plan = cp.plan_conv(3, 3, padding=1)
+    packed = plan.pack(wt)
+    out = torch.empty([n, co, h, w], device=DEV, dtype=torch.bfloat16)
+    rsum = torch.empty([n, co], device=DEV)
+    free_before = torch.cuda.mem_get_info()[0]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cp.conv2d(x, packed, plan, co, reduce_x=rx, out=out, reduce_sum=rsum)
+    for trial in range(3):
+        x.copy_(torch.randn([n, ci, h, w], device=DEV, generator=g).to(torch.bfloat16))
+        rsum.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        y0, r0 = cp.conv2d(x, packed, plan, co, reduce_x=rx)
+        assert torch.equal(out, y0), trial
+        scale = float(r0.abs().max())
+        assert float((rsum - r0).abs().max()) <= 1e-5 * scale, (trial, float((rsum - r0).abs().max()), scale)
+    del graph
+    # nothing was allocated behind torch's back either (the driver's own view of the device's free memory; torch's
+    # allocator may have cached blocks of its own, which only lowers the figure by what the test itself asked for)
+    assert free_before - torch.cuda.mem_get_info()[0] < (64 << 20)
