@@ -23,7 +23,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <cstdlib>
 
 namespace sg {
 namespace {
@@ -69,12 +68,6 @@ __device__ __forceinline__ int swz(int row, int byte) {
     return row * kRow + ((((byte >> 4) ^ (row >> 1)) & 3) << 4) + (byte & 15);
 }
 
-template <class T> __device__ __forceinline__ float lo16(unsigned w) { return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(w & 0xffffu))); }
-template <class T> __device__ __forceinline__ float hi16(unsigned w) { return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(w >> 16))); }
-template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) {
-    return (unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(a)) |
-           ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
-}
 
 // Two 16-bit elements in a dword <-> two floats (one conversion instruction for the pair).
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -96,6 +89,10 @@ template <> struct Pair<__half> {
         return __builtin_bit_cast(unsigned, v);
     }
 };
+
+template <class T> __device__ __forceinline__ float lo16(unsigned w) { return Pair<T>::lo(w); }
+template <class T> __device__ __forceinline__ float hi16(unsigned w) { return Pair<T>::hi(w); }
+template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) { return Pair<T>::pack(a, b); }
 
 // Buffer addressing: a resource descriptor bounds every access to `bytes` from its base; a byte offset at or beyond the
 // bound reads zeros.  A packet outside the image (or a channel beyond the last) therefore costs no branch and no
@@ -365,8 +362,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
 // the multiply phase.  CHUNKS = ceil(ci / 32), M_TILES = ceil(co / 16).  STEP = 2 (one chunk only: the strided
 // layer behind the blur of the discriminator's first block, 32 -> 64 channels) has the LDS of a CU to itself; the
 // general kernel would run it one tile per workgroup with nothing in flight while it multiplies.
-template <class T, int CHUNKS, int M_TILES, int STEP = 1>
-__global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1) ? 2 : 1) conv3x3_resident_kernel(Conv3x3Args g, int units) {
+template <class T, int CHUNKS, int M_TILES, int STEP, bool MOD>
+__global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES <= 2) ? 2 : 1) conv3x3_resident_kernel(Conv3x3Args g, int units) {
     using G = Geo<STEP>;
     constexpr int NV = G::NV, LWP = G::LWP, BMW = 16 * M_TILES;
     constexpr int kWChunk = 9 * BMW * kRow;
@@ -388,9 +385,25 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1) ? 2 : 1) 
         *reinterpret_cast<uint4*>(s_w + ch * kWChunk + swz(row, slot * 16)) = v;
     }
 
-    // ---- input fetch / commit: as conv3x3_kernel, all chunks of a tile at once ---------------------------------
+    // ---- input fetch / commit: as conv3x3_kernel, all chunks of a tile at once.  What does not depend on the tile
+    // (an item's row and packet inside the footprint, its place in the LDS image) is decided here; per tile a lane
+    // decides once per item whether the packet lies in the image (else its offset is kOutside: the load returns zeros).
     const int cg = tid & 15, slot0 = tid >> 4;
-    uint4 va[CHUNKS][G::STEPS], vb[CHUNKS][G::STEPS];
+    constexpr int STEPS = G::STEPS;
+    constexpr bool LAST_PARTIAL = (G::ITEMS % 16) != 0;
+    const bool last_item = !LAST_PARTIAL || slot0 + 16 * (STEPS - 1) < G::ITEMS;
+    int item_ry[STEPS], item_px[STEPS];
+#pragma unroll
+    for (int q = 0; q < STEPS; q++) {
+        const int item = slot0 + 16 * q;
+        item_ry[q] = (item < G::ITEMS) ? item / NV : (1 << 20);     // an item that does not exist lies below any image
+        item_px[q] = (item % NV) * 8;
+    }
+    int st_addr[4];
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) st_addr[jp] = slot0 * 8 * kRow + swz(2 * jp, cg * 4);
+    const unsigned plane_bytes = (unsigned)plane * 2u;
+    uint4 va[CHUNKS][STEPS], vb[CHUNKS][STEPS];
     float s0[CHUNKS], s1[CHUNKS];
     auto decode = [&](int unit, int& n, int& a0, int& b0) {
         const int tb = unit % g.tiles_b; unit /= g.tiles_b;
@@ -401,29 +414,28 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1) ? 2 : 1) 
     auto fetch = [&](int unit) {
         int n, a0, b0;
         decode(unit, n, a0, b0);
-        const T* x = (const T*)g.x + (unsigned)(n * g.ci * plane);
+        const T* xs = (const T*)g.x + (unsigned)(n * g.ci * plane);
+        const int iy_first = a0 * STEP + g.dy0, px_first = b0 * STEP + g.px_shift;
+        unsigned voff[STEPS];
+#pragma unroll
+        for (int q = 0; q < STEPS; q++) {
+            const int iy = iy_first + item_ry[q], px0 = px_first + item_px[q];
+            const bool ok = iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
+            voff[q] = ok ? (unsigned)(2 * cg * plane + iy * g.wid + px0) * 2u : kOutside;
+        }
 #pragma unroll
         for (int ch = 0; ch < CHUNKS; ch++) {
-            const int c = ch * KCH + 2 * cg;
-            const bool c_ok = c < g.ci, two = c + 1 < g.ci;
-            const T* src0 = x + (unsigned)(c * plane);
+            const int left = min(KCH, g.ci - ch * KCH);
+            const rsrc_t rx = make_rsrc(xs + (size_t)ch * KCH * plane, (unsigned)max(left, 0) * plane_bytes);
 #pragma unroll
-            for (int q = 0; q < G::STEPS; q++) {
-                const int item = slot0 + 16 * q;
-                const int ry = item / NV, v = item - ry * NV;
-                const int iy = a0 * STEP + g.dy0 + ry, px0 = b0 * STEP + g.px_shift + v * 8;
-                va[ch][q] = make_uint4(0, 0, 0, 0);
-                vb[ch][q] = make_uint4(0, 0, 0, 0);
-                if (c_ok && item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
-                    const T* src = src0 + iy * g.wid + px0;
-                    va[ch][q] = *reinterpret_cast<const uint4*>(src);
-                    if (two) vb[ch][q] = *reinterpret_cast<const uint4*>(src + plane);
-                }
+            for (int q = 0; q < STEPS; q++) {
+                va[ch][q] = load16(rx, voff[q], 0);
+                vb[ch][q] = load16(rx, voff[q], plane_bytes);
             }
-            s0[ch] = 1.f; s1[ch] = 1.f;
-            if (g.in_scale) {
-                s0[ch] = c_ok ? g.in_scale[n * g.ci + c] : 0.f;
-                s1[ch] = two ? g.in_scale[n * g.ci + c + 1] : 0.f;
+            if constexpr (MOD) {
+                const rsrc_t rs = make_rsrc(g.in_scale + (size_t)n * g.ci + ch * KCH, (unsigned)max(left, 0) * 4u);
+                s0[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 0, 0));
+                s1[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 4, 0));
             }
         }
     };
@@ -431,19 +443,23 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1) ? 2 : 1) 
 #pragma unroll
         for (int ch = 0; ch < CHUNKS; ch++)
 #pragma unroll
-            for (int q = 0; q < G::STEPS; q++) {
-                const int item = slot0 + 16 * q;
-                if (item >= G::ITEMS) continue;
+            for (int q = 0; q < STEPS; q++) {
+                if (LAST_PARTIAL && q == STEPS - 1 && !last_item) continue;
                 const unsigned wa[4] = {va[ch][q].x, va[ch][q].y, va[ch][q].z, va[ch][q].w};
                 const unsigned wb[4] = {vb[ch][q].x, vb[ch][q].y, vb[ch][q].z, vb[ch][q].w};
-                const int r0 = item * 8;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
-                    unsigned out;
-                    if (g.in_scale) out = pack16<T>(lo16<T>(ea) * s0[ch], lo16<T>(eb) * s1[ch]);
-                    else out = (ea & 0xffffu) | (eb << 16);
-                    *reinterpret_cast<unsigned*>(s_in + ch * G::kInBytes + swz(r0 + j, cg * 4)) = out;
+                for (int jp = 0; jp < 4; jp++) {
+                    unsigned e0, e1;
+                    if constexpr (MOD) {
+                        e0 = Pair<T>::pack(Pair<T>::lo(wa[jp]) * s0[ch], Pair<T>::lo(wb[jp]) * s1[ch]);
+                        e1 = Pair<T>::pack(Pair<T>::hi(wa[jp]) * s0[ch], Pair<T>::hi(wb[jp]) * s1[ch]);
+                    } else {
+                        e0 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x05040100u);
+                        e1 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x07060302u);
+                    }
+                    unsigned char* dst = s_in + ch * G::kInBytes + st_addr[jp] + q * (16 * 8 * kRow);
+                    *reinterpret_cast<unsigned*>(dst) = e0;
+                    *reinterpret_cast<unsigned*>(dst + kRow) = e1;
                 }
             }
     };
@@ -611,17 +627,23 @@ int compute_units() {   // of the current device; asked once per process and dev
     return cu;
 }
 
-template <class T, int CHUNKS, int M_TILES, int STEP = 1>
-static int launch_resident(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
+template <class T, int CHUNKS, int M_TILES, int STEP, bool MOD>
+static int launch_resident_mod(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
     constexpr size_t lds = (size_t)CHUNKS * (9 * 16 * M_TILES * kRow + Geo<STEP>::kInBytes);
     static_assert(lds <= 160 * 1024, "weights and tile do not fit the LDS of a CU");
-    auto kernel = conv3x3_resident_kernel<T, CHUNKS, M_TILES, STEP>;
+    auto kernel = conv3x3_resident_kernel<T, CHUNKS, M_TILES, STEP, MOD>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     const int per_cu = (CHUNKS == 1) ? std::min<int>(2, (int)((160 * 1024) / lds)) : 1;
     const int64_t grid = std::max<int64_t>(8, std::min<int64_t>((units + 7) / 8 * 8, (int64_t)per_cu * compute_units()) / 8 * 8);   // a multiple of the 8 XCDs
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kThreads), lds, stream, g, (int)units);
     return check_launch("sg_conv2d");
+}
+
+template <class T, int CHUNKS, int M_TILES, int STEP = 1>
+static int launch_resident(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
+    return g.in_scale ? launch_resident_mod<T, CHUNKS, M_TILES, STEP, true>(g, units, stream)
+                      : launch_resident_mod<T, CHUNKS, M_TILES, STEP, false>(g, units, stream);
 }
 
 template <class T>
@@ -650,8 +672,6 @@ static int launch_step(Conv3x3Args g, hipStream_t stream) {
 // Layers with more than 64 output channels take the 8-wave form (128 channels per workgroup).
 template <class T, bool MOD>
 static int launch_wide_or_not_mod(const Conv3x3Args& g, int step, hipStream_t stream) {
-    static const bool force4 = getenv("SG_CONV3X3_WAVES4") != nullptr;   // EXPERIMENT
-    if (force4) return step == 1 ? launch_step<T, 1, 4, MOD>(g, stream) : launch_step<T, 2, 4, MOD>(g, stream);
     if (step == 1) return (g.co > BM) ? launch_step<T, 1, 8, MOD>(g, stream) : launch_step<T, 1, 4, MOD>(g, stream);
     return (g.co > BM) ? launch_step<T, 2, 8, MOD>(g, stream) : launch_step<T, 2, 4, MOD>(g, stream);
 }
