@@ -15,6 +15,8 @@
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
+#include <type_traits>
+
 namespace sg {
 namespace {
 
@@ -35,7 +37,8 @@ template <int STEP> struct WGeo {
     static constexpr int LH = (TH - 1) * STEP + 3;             // input footprint: 10 x 34 / 9 x 65 pixels
     static constexpr int LW = (TW - 1) * STEP + 3;
     static constexpr int NV = (LW + 7 + 7) / 8;                // 8-pixel packets covering a footprint row at any alignment
-    static constexpr int kXBytes = LH * LW * kPitch;           // 54400 / 93600
+    static constexpr int LWP = NV * 8;                         // pixels per image row: whole packets (48 / 72), so that a commit needs no column test
+    static constexpr int kXBytes = LH * LWP * kPitch;          // 76800 / 103680
     static constexpr int kGBytes = TH * TW * kPitch;           // 40960 / 20480
     static constexpr int X_STEPS = (LH * NV + 7) / 8;          // (row, packet) items per lane: 8 / 11
     static constexpr int G_STEPS = TH * (TW / 8) / 8;          // 4 / 2
@@ -53,10 +56,38 @@ template <> struct Mma16<__half> {
     }
 };
 
-template <class T> __device__ __forceinline__ float lo16(unsigned w) { return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(w & 0xffffu))); }
-template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) {
-    return (unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(a)) |
-           ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
+// Two 16-bit elements in a dword <-> two floats (one conversion instruction for the pair).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <class T> struct Pair;
+template <> struct Pair<__hip_bfloat16> {
+    static __device__ __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        const bf16x2_t v = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
+template <> struct Pair<__half> {
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        const f16x2_t v = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
+
+// Buffer addressing: a byte offset at or beyond the descriptor's bound reads zeros, so a packet outside the image (or a
+// channel beyond the last) costs one select on its offset when the tile is decoded, and nothing afterwards.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutside = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 load16(rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // 8 consecutive K values (pixels) of one channel for this lane: two transposing reads of 4 pixel rows each
@@ -79,12 +110,13 @@ struct Wgrad3x3Args {
 
 // WAVES = 8: waves 4..7 work on the sub-blocks of waves 0..3 and take every other k-step of theirs (two waves per
 // SIMD: one's LDS reads and staging arithmetic run under the other's multiplies; the partial sums meet in the atomics).
-template <class T, int STEP, int WAVES = 4>
+template <class T, int STEP, int WAVES, bool XS, bool GS>   // XS / GS: x / g carry a per-sample channel scale
 __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p) {
     using G = WGeo<STEP>;
-    constexpr int TH = G::TH, LH = G::LH, LW = G::LW, NV = G::NV;
+    constexpr int TH = G::TH, LH = G::LH, NV = G::NV, LWP = G::LWP;
     constexpr int ROWS = 2 * WAVES;                                   // item rows staged per step (32 lanes per row)
-    constexpr int X_STEPS = (LH * NV + ROWS - 1) / ROWS, G_STEPS = (TH * (TW / 8) + ROWS - 1) / ROWS;
+    constexpr int X_ITEMS = LH * NV, G_ITEMS = TH * (TW / 8);
+    constexpr int X_STEPS = (X_ITEMS + ROWS - 1) / ROWS, G_STEPS = (G_ITEMS + ROWS - 1) / ROWS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_x = smem;
     unsigned char* s_g = smem + G::kXBytes;
@@ -94,9 +126,28 @@ __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p)
     const T* __restrict__ x = (const T*)p.x;
     const T* __restrict__ g = (const T*)p.g;
     const int x_plane = p.h * p.wid, g_plane = p.gh * p.gw;
+    const unsigned x_plane_bytes = (unsigned)x_plane * 2u, g_plane_bytes = (unsigned)g_plane * 2u;
+    const int x_left = min(BC, p.cx - cx0), g_left = min(BC, p.cg - cg0);   // real channels of this block
 
-    // ---- fetch / commit: item = (channel pair cp = tid & 31, packet, row) --------------------------------------
-    const int cp = tid & 31;
+    // ---- fetch / commit: item = (channel pair cp = tid & 31, (row, packet) index r) ------------------------------
+    // What does not depend on the tile is decided here: an item's row and first pixel inside the footprint, its
+    // LDS address, whether it exists.  Per tile a lane decides once per item whether its packet lies in the image.
+    const int cp = tid & 31, r0 = tid >> 5;
+    int x_ry[X_STEPS], x_px[X_STEPS], g_ra[G_STEPS], g_pb[G_STEPS];
+#pragma unroll
+    for (int s = 0; s < X_STEPS; s++) {
+        const int r = r0 + ROWS * s;
+        x_ry[s] = (r < X_ITEMS) ? r / NV : (1 << 20);     // an item that does not exist lies below any image
+        x_px[s] = (r % NV) * 8;
+    }
+#pragma unroll
+    for (int s = 0; s < G_STEPS; s++) {
+        const int r = r0 + ROWS * s;
+        g_ra[s] = (r < G_ITEMS) ? (r >> 2) : (1 << 20);
+        g_pb[s] = (r & 3) * 8;
+    }
+    const bool x_last = (X_ITEMS % ROWS) == 0 || r0 + ROWS * (X_STEPS - 1) < X_ITEMS;
+    const bool g_last = (G_ITEMS % ROWS) == 0 || r0 + ROWS * (G_STEPS - 1) < G_ITEMS;
     uint4 xa[X_STEPS], xb[X_STEPS], ga[G_STEPS], gb[G_STEPS];
     float xs0 = 1.f, xs1 = 1.f, gs0 = 1.f, gs1 = 1.f;
 
@@ -106,76 +157,68 @@ __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p)
         const int n = tile / p.tiles_a;
         const int a0 = ta * TH, b0 = tb * TW;
         {
-            const int c = cx0 + 2 * cp;
-            const bool c_ok = c < p.cx, two = c + 1 < p.cx;
-            const T* base = x + (unsigned)((n * p.cx + c) * x_plane);
+            const rsrc_t rx = make_rsrc(x + (size_t)(n * p.cx + cx0) * x_plane, (unsigned)x_left * x_plane_bytes);
+            const int iy_first = a0 * STEP + p.dy0, px_first = b0 * STEP + p.px_shift;
 #pragma unroll
             for (int s = 0; s < X_STEPS; s++) {
-                const int r = (tid >> 5) + ROWS * s;          // item row index = ry * NV + v
-                const int v = r % NV, ry = r / NV;
-                const int iy = a0 * STEP + p.dy0 + ry, px0 = b0 * STEP + p.px_shift + v * 8;
-                xa[s] = make_uint4(0, 0, 0, 0);
-                xb[s] = make_uint4(0, 0, 0, 0);
-                if (c_ok && ry < LH && iy >= 0 && iy < p.h && px0 >= 0 && px0 < p.wid) {
-                    const T* src = base + iy * p.wid + px0;
-                    xa[s] = *reinterpret_cast<const uint4*>(src);
-                    if (two) xb[s] = *reinterpret_cast<const uint4*>(src + x_plane);
-                }
+                const int iy = iy_first + x_ry[s], px0 = px_first + x_px[s];
+                const bool ok = iy >= 0 && iy < p.h && px0 >= 0 && px0 < p.wid;
+                const unsigned voff = ok ? (unsigned)(2 * cp * x_plane + iy * p.wid + px0) * 2u : kOutside;
+                xa[s] = load16(rx, voff, 0);
+                xb[s] = load16(rx, voff, x_plane_bytes);              // channel 2 cp + 1 (channel counts are multiples of 8)
             }
-            if (p.x_scale) {
-                xs0 = c_ok ? p.x_scale[n * p.cx + c] : 0.f;
-                xs1 = two ? p.x_scale[n * p.cx + c + 1] : 0.f;
+            if constexpr (XS) {
+                const rsrc_t rs = make_rsrc(p.x_scale + (size_t)n * p.cx + cx0, (unsigned)x_left * 4u);
+                xs0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 0, 0));
+                xs1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 4, 0));
             }
         }
         {
-            const int c = cg0 + 2 * cp;
-            const bool c_ok = c < p.cg, two = c + 1 < p.cg;
-            const T* base = g + (unsigned)((n * p.cg + c) * g_plane);
+            const rsrc_t rg = make_rsrc(g + (size_t)(n * p.cg + cg0) * g_plane, (unsigned)g_left * g_plane_bytes);
 #pragma unroll
             for (int s = 0; s < G_STEPS; s++) {
-                const int r = (tid >> 5) + ROWS * s;          // = ra * 4 + v
-                const int v = r & 3, ra = r >> 2;
-                const int a = a0 + ra, b = b0 + v * 8;
-                ga[s] = make_uint4(0, 0, 0, 0);
-                gb[s] = make_uint4(0, 0, 0, 0);
-                if (c_ok && ra < TH && a < p.gh && b < p.gw) {
-                    const T* src = base + a * p.gw + b;
-                    ga[s] = *reinterpret_cast<const uint4*>(src);
-                    if (two) gb[s] = *reinterpret_cast<const uint4*>(src + g_plane);
-                }
+                const int a = a0 + g_ra[s], b = b0 + g_pb[s];
+                const bool ok = a < p.gh && b < p.gw;
+                const unsigned voff = ok ? (unsigned)(2 * cp * g_plane + a * p.gw + b) * 2u : kOutside;
+                ga[s] = load16(rg, voff, 0);
+                gb[s] = load16(rg, voff, g_plane_bytes);
             }
-            if (p.g_scale) {
-                gs0 = c_ok ? p.g_scale[n * p.cg + c] : 0.f;
-                gs1 = two ? p.g_scale[n * p.cg + c + 1] : 0.f;
+            if constexpr (GS) {
+                const rsrc_t rs = make_rsrc(p.g_scale + (size_t)n * p.cg + cg0, (unsigned)g_left * 4u);
+                gs0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 0, 0));
+                gs1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 4, 0));
             }
         }
     };
 
-    auto put8 = [&](unsigned char* dst_row0, const uint4& a, const uint4& b, bool scaled, float s0, float s1, int first, int count) {
-        // pixels first .. first + 7 of one channel pair -> rows dst_row0 + j * pitch, rows outside [0, count) skipped
+    // pixels 0 .. 7 of one channel pair -> rows dst + j * pitch (the image rows hold whole packets: no column test)
+    auto put8 = [&](unsigned char* dst, const uint4& a, const uint4& b, auto scaled, float s0, float s1) {
         const unsigned wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
-            const unsigned out = scaled ? pack16<T>(lo16<T>(ea) * s0, lo16<T>(eb) * s1) : ((ea & 0xffffu) | (eb << 16));
-            const int col = first + j;
-            if (col >= 0 && col < count) *reinterpret_cast<unsigned*>(dst_row0 + col * kPitch + cp * 4) = out;
+        for (int jp = 0; jp < 4; jp++) {
+            unsigned e0, e1;
+            if constexpr (decltype(scaled)::value) {
+                e0 = Pair<T>::pack(Pair<T>::lo(wa[jp]) * s0, Pair<T>::lo(wb[jp]) * s1);
+                e1 = Pair<T>::pack(Pair<T>::hi(wa[jp]) * s0, Pair<T>::hi(wb[jp]) * s1);
+            } else {
+                e0 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x05040100u);
+                e1 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x07060302u);
+            }
+            *reinterpret_cast<unsigned*>(dst + (2 * jp) * kPitch) = e0;
+            *reinterpret_cast<unsigned*>(dst + (2 * jp + 1) * kPitch) = e1;
         }
     };
 
     auto commit = [&]() {
 #pragma unroll
         for (int s = 0; s < X_STEPS; s++) {
-            const int r = (tid >> 5) + ROWS * s;
-            const int v = r % NV, ry = r / NV;
-            if (ry < LH) put8(s_x + ry * LW * kPitch, xa[s], xb[s], p.x_scale != nullptr, xs0, xs1, v * 8 - p.px_col, LW);
+            if (s == X_STEPS - 1 && !x_last) continue;
+            put8(s_x + (r0 + ROWS * s) * 8 * kPitch + cp * 4, xa[s], xb[s], std::integral_constant<bool, XS>{}, xs0, xs1);   // row ry, packet v: pixel (ry * NV + v) * 8
         }
 #pragma unroll
         for (int s = 0; s < G_STEPS; s++) {
-            const int r = (tid >> 5) + ROWS * s;
-            const int v = r & 3, ra = r >> 2;
-            if (ra >= TH) continue;
-            put8(s_g + ra * TW * kPitch, ga[s], gb[s], p.g_scale != nullptr, gs0, gs1, v * 8, TW);
+            if (s == G_STEPS - 1 && !g_last) continue;
+            put8(s_g + (r0 + ROWS * s) * 8 * kPitch + cp * 4, ga[s], gb[s], std::integral_constant<bool, GS>{}, gs0, gs1);   // row ra, packet v: pixel (ra * 4 + v) * 8
         }
     };
 
@@ -201,7 +244,7 @@ __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p)
     for (int hf = 0; hf < 2; hf++) {
         const int col = 4 * lgrp + 16 * hf + q;
         off_g[hf] = col * kPitch + pq * 8 + wm * 64;   // + m * 32 + ks * TW * kPitch
-        off_x[hf] = col * STEP * kPitch + pq * 8 + wn * 64;   // + n * 32 + ((ks * STEP + ky) * LW + kx) * kPitch
+        off_x[hf] = (col * STEP + p.px_col) * kPitch + pq * 8 + wn * 64;   // + n * 32 + ((ks * STEP + ky) * LWP + kx) * kPitch
     }
 
     f32x4_t acc[9][2][2];
@@ -232,7 +275,7 @@ __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p)
                 const int ky = tp / 3, kx = tp % 3;
 #pragma unroll
                 for (int n = 0; n < 2; n++) {
-                    const unsigned char* base = s_x + ((ks * STEP + ky) * LW + kx) * kPitch + n * 32;
+                    const unsigned char* base = s_x + ((ks * STEP + ky) * LWP + kx) * kPitch + n * 32;
                     const uint4 b = fetch_frag(base + off_x[0], base + off_x[1]);
 #pragma unroll
                     for (int m = 0; m < 2; m++) Mma16<T>::run(a[m], b, acc[tp][m][n]);
@@ -265,11 +308,13 @@ bool wgrad3x3_eligible(const sg_conv2d_wgrad_params& p) {
     if (p.w_in % 8 != 0 || p.gw % 8 != 0) return false;
     if (!aligned16(p.x) || !aligned16(p.g)) return false;
     if (p.cx < 32 || p.cg < 32) return false;   // a 64 x 64 block would be mostly padding
+    if (p.cx % 8 != 0 || p.cg % 8 != 0) return false;
+    if ((int64_t)p.h * p.w_in >= (1 << 23) || (int64_t)p.gh * p.gw >= (1 << 23)) return false;   // 64 planes bound the buffer offsets (< 2^31 bytes)
     return true;
 }
 
-template <class T, int STEP>
-static int launch_wstep(Wgrad3x3Args& a, const sg_conv2d_wgrad_params& p, hipStream_t stream) {
+template <class T, int STEP, bool XS, bool GS>
+static int launch_wstep_scaled(Wgrad3x3Args& a, const sg_conv2d_wgrad_params& p, hipStream_t stream) {
     using G = WGeo<STEP>;
     a.tiles_a = (p.gh + G::TH - 1) / G::TH;
     a.tiles_b = (p.gw + TW - 1) / TW;
@@ -282,12 +327,21 @@ static int launch_wstep(Wgrad3x3Args& a, const sg_conv2d_wgrad_params& p, hipStr
     if (split > tiles) split = tiles;
     if (split < 1) split = 1;
     constexpr size_t lds = G::kXBytes + G::kGBytes;
-    constexpr int WAVES = (STEP == 1) ? 8 : 4;   // (the strided form spills registers with two waves per SIMD and loses)
-    auto kernel = wgrad3x3_kernel<T, STEP, WAVES>;
+    constexpr int WAVES = (STEP == 1) ? 8 : 4;   // (the strided form with two waves per SIMD: 300-410 against 340-470 TFLOP/s)
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS of a CU");
+    auto kernel = wgrad3x3_kernel<T, STEP, WAVES, XS, GS>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     hipLaunchKernelGGL(kernel, dim3((unsigned)split, (unsigned)blocks_g, (unsigned)blocks_x), dim3(64 * WAVES), lds, stream, a);
     return check_launch("sg_conv2d_wgrad");
+}
+
+template <class T, int STEP>
+static int launch_wstep(Wgrad3x3Args& a, const sg_conv2d_wgrad_params& p, hipStream_t stream) {
+    if (p.x_scale && p.g_scale) return launch_wstep_scaled<T, STEP, true, true>(a, p, stream);
+    if (p.x_scale) return launch_wstep_scaled<T, STEP, true, false>(a, p, stream);
+    if (p.g_scale) return launch_wstep_scaled<T, STEP, false, true>(a, p, stream);
+    return launch_wstep_scaled<T, STEP, false, false>(a, p, stream);
 }
 
 int wgrad3x3_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
