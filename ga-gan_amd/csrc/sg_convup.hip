@@ -57,10 +57,39 @@ template <> struct Mma16<__half> {
 __device__ __forceinline__ int swz(int row, int byte) {
     return row * kRow + ((((byte >> 4) ^ (row >> 1)) & 3) << 4) + (byte & 15);
 }
-template <class T> __device__ __forceinline__ float lo16(unsigned w) { return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(w & 0xffffu))); }
-template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) {
-    return (unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(a)) |
-           ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
+// Two 16-bit elements in a dword <-> two floats (one conversion instruction for the pair).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <class T> struct Pair;
+template <> struct Pair<__hip_bfloat16> {
+    static __device__ __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        const bf16x2_t v = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
+template <> struct Pair<__half> {
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        const f16x2_t v = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
+template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) { return Pair<T>::pack(a, b); }
+
+// Buffer addressing: a byte offset at or beyond the descriptor's bound reads zeros (packets outside the image, channels
+// beyond the last): decided once per workgroup, no branch in the K loop.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutside = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 load16(rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 struct ConvUpArgs {
@@ -69,14 +98,16 @@ struct ConvUpArgs {
     int n, ci, co, h, wid, oh, ow;
     int w_offset0, w_offset1, w_offset2, w_offset3;   // start of each phase's taps in the packed weights (elements)
     int tiles_a, tiles_b, units;
+    unsigned w_bytes;                                  // bytes of the packed weights
 };
 
 // WAVES = 8 (layers with more than 32 output channels): 64 output channels per workgroup - waves 4..7 multiply the
-// same staged pixels with the second 32 channels; one such workgroup per CU, two waves per SIMD.
-template <class T, int WAVES = 4>
+// same staged pixels with the second 32 channels; one such workgroup per CU, two waves per SIMD.  MOD: in_scale given.
+template <class T, int WAVES, bool MOD>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) conv_up2_kernel(ConvUpArgs g) {
     constexpr int BCOT = BCO * (WAVES / 4);                                    // output channels per workgroup
     constexpr int SLOTS = 4 * WAVES, STEPS = (ITEMS + SLOTS - 1) / SLOTS;      // staging: item slots, items per lane
+    constexpr bool LAST_PARTIAL = (ITEMS % SLOTS) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_in = smem;
     unsigned char* s_w = smem + kInBytes;
@@ -94,75 +125,95 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) conv_up2_kerne
     const int m0 = (unit / g.n) * BCOT;
     const int a0 = ta * TH, b0 = tb * TW;
     const int plane = g.h * g.wid;
-    const T* __restrict__ x = (const T*)g.x + (unsigned)(n * g.ci * plane);
+    const unsigned plane_bytes = (unsigned)plane * 2u;
+    const T* __restrict__ xs = (const T*)g.x + (unsigned)(n * g.ci * plane);
     const T* __restrict__ w = (const T*)g.w;
 
+    // ---- staging plan, decided once: which packets a lane moves (kOutside: outside the image), where they land -----
     const int cg = tid & 15, slot0 = tid >> 4;
-    uint4 va[STEPS], vb[STEPS];
-    float s0 = 1.f, s1 = 1.f;
-
-    auto fetch = [&](int c0) {
-        const int c = c0 + 2 * cg;
-        const bool c_ok = c < g.ci, two = c + 1 < g.ci;
-        const T* src0 = x + (unsigned)(c * plane);
+    unsigned voff[STEPS];
 #pragma unroll
-        for (int q = 0; q < STEPS; q++) {
-            const int item = slot0 + SLOTS * q;
-            const int ry = item / NV, v = item - ry * NV;
-            const int iy = a0 - 1 + ry, px0 = b0 - 8 + v * 8;
-            va[q] = make_uint4(0, 0, 0, 0);
-            vb[q] = make_uint4(0, 0, 0, 0);
-            if (c_ok && item < ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
-                const T* src = src0 + iy * g.wid + px0;
-                va[q] = *reinterpret_cast<const uint4*>(src);
-                if (two) vb[q] = *reinterpret_cast<const uint4*>(src + plane);
-            }
-        }
-        if (g.in_scale) {
-            s0 = c_ok ? g.in_scale[n * g.ci + c] : 0.f;
-            s1 = two ? g.in_scale[n * g.ci + c + 1] : 0.f;
-        }
-    };
-    auto commit = [&]() {
+    for (int q = 0; q < STEPS; q++) {
+        const int item = slot0 + SLOTS * q;
+        const int ry = item / NV, v = item - ry * NV;
+        const int iy = a0 - 1 + ry, px0 = b0 - 8 + v * 8;
+        const bool ok = item < ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
+        voff[q] = ok ? (unsigned)(2 * cg * plane + iy * g.wid + px0) * 2u : kOutside;
+    }
+    const bool last_item = !LAST_PARTIAL || slot0 + SLOTS * (STEPS - 1) < ITEMS;
+    int st_addr[4];
 #pragma unroll
-        for (int q = 0; q < STEPS; q++) {
-            const int item = slot0 + SLOTS * q;
-            if (item >= ITEMS) continue;
-            const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
-            const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
-            const int r0 = item * 8;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const unsigned ea = wa[j >> 1] >> (16 * (j & 1)), eb = wb[j >> 1] >> (16 * (j & 1));
-                unsigned out;
-                if (g.in_scale) out = pack16<T>(lo16<T>(ea) * s0, lo16<T>(eb) * s1);
-                else out = (ea & 0xffffu) | (eb << 16);
-                *reinterpret_cast<unsigned*>(s_in + swz(r0 + j, cg * 4)) = out;
-            }
-        }
-    };
-    // weights of a chunk: cache-resident (every workgroup reads them), fetched right before use.  Waves 0-1 take the
-    // even combinations, waves 2-3 the odd ones; a lane moves one 16-byte packet of one output channel per step.
-    auto stage_weights = [&](int c0) {
+    for (int jp = 0; jp < 4; jp++) st_addr[jp] = slot0 * 8 * kRow + swz(2 * jp, cg * 4);
+    // weights of a chunk: waves 0-1 (of each half) take the even (phase, tap) combinations, waves 2-3 the odd ones; a lane
+    // moves one 16-byte packet of one output channel per combination
+    constexpr int WQ = 5;
+    unsigned w_voff[WQ];
+    int w_st[WQ];
+    const int w_slot = tid & 3;
+    {
         constexpr Combo kc[kCombos + 1] = {{0, 0, 0, -1, -1}, {0, 0, 1, -1, 0}, {0, 1, 0, 0, -1}, {0, 1, 1, 0, 0}, {1, 0, 0, -1, 0},
                                            {1, 1, 0, 0, 0}, {2, 0, 0, 0, -1}, {2, 0, 1, 0, 0}, {3, 0, 0, 0, 0}, {3, 0, 0, 0, 0}};
         constexpr int nkx[4] = {2, 1, 2, 1};
         const bool odd = (tid & 255) >= 128;
-        const int o_local = ((tid >> 2) & 31) + 32 * half, slot = tid & 3;
-        const int o = m0 + o_local, cw = c0 + slot * 8;
-        const bool ok = o < g.co && cw < g.ci;
+        const int o_local = ((tid >> 2) & 31) + 32 * half;
+        const int o = m0 + o_local;
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
+        for (int q = 0; q < WQ; q++) {
             const int combo = 2 * q + (odd ? 1 : 0);
             const int phase = odd ? kc[2 * q + 1].phase : kc[2 * q].phase;
             const int tap = odd ? kc[2 * q + 1].ty * nkx[kc[2 * q + 1].phase] + kc[2 * q + 1].tx
                                 : kc[2 * q].ty * nkx[kc[2 * q].phase] + kc[2 * q].tx;
             const int w_off = phase == 0 ? g.w_offset0 : phase == 1 ? g.w_offset1 : phase == 2 ? g.w_offset2 : g.w_offset3;
-            if (combo >= kCombos) continue;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(w + (unsigned)(w_off + (tap * g.co + o) * g.ci + cw));
-            *reinterpret_cast<uint4*>(s_w + swz(combo * BCOT + o_local, slot * 16)) = v;
+            w_voff[q] = (combo < kCombos && o < g.co) ? (unsigned)(w_off + (tap * g.co + o) * g.ci + w_slot * 8) * 2u : kOutside;
+            w_st[q] = (combo < kCombos) ? swz(combo * BCOT + o_local, w_slot * 16) : -1;
         }
+    }
+
+    uint4 va[STEPS], vb[STEPS], vw[WQ];
+    float s0 = 1.f, s1 = 1.f;
+
+    auto fetch = [&](int c0) {
+        const int left = min(KCH, g.ci - c0);
+        const rsrc_t rx = make_rsrc(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
+#pragma unroll
+        for (int q = 0; q < STEPS; q++) {
+            va[q] = load16(rx, voff[q], 0);
+            vb[q] = load16(rx, voff[q], plane_bytes);
+        }
+        if constexpr (MOD) {
+            const rsrc_t rs = make_rsrc(g.in_scale + (size_t)n * g.ci + c0, (unsigned)left * 4u);
+            s0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 0, 0));
+            s1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 4, 0));
+        }
+        const rsrc_t rw = make_rsrc(w + c0, (unsigned)g.w_bytes);
+        const bool slot_ok = w_slot * 8 < left;
+#pragma unroll
+        for (int q = 0; q < WQ; q++) vw[q] = load16(rw, slot_ok ? w_voff[q] : kOutside, 0);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < STEPS; q++) {
+            if (LAST_PARTIAL && q == STEPS - 1 && !last_item) continue;
+            const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
+            const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
+#pragma unroll
+            for (int jp = 0; jp < 4; jp++) {
+                unsigned e0, e1;
+                if constexpr (MOD) {
+                    e0 = Pair<T>::pack(Pair<T>::lo(wa[jp]) * s0, Pair<T>::lo(wb[jp]) * s1);
+                    e1 = Pair<T>::pack(Pair<T>::hi(wa[jp]) * s0, Pair<T>::hi(wb[jp]) * s1);
+                } else {
+                    e0 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x05040100u);
+                    e1 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x07060302u);
+                }
+                unsigned char* dst = s_in + st_addr[jp] + q * (SLOTS * 8 * kRow);
+                *reinterpret_cast<unsigned*>(dst) = e0;
+                *reinterpret_cast<unsigned*>(dst + kRow) = e1;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++)
+            if (w_st[q] >= 0) *reinterpret_cast<uint4*>(s_w + w_st[q]) = vw[q];
     };
 
     // n-tile j of wave w: tile row 2w + (j >> 1), columns 16 (j & 1) .. +15; LDS row of input (a + dy, b + dx):
@@ -211,7 +262,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) conv_up2_kerne
     fetch(0);
     for (int c0 = 0; c0 < g.ci; c0 += KCH) {
         __syncthreads();
-        stage_weights(c0);
         commit();
         __syncthreads();
         if (c0 + KCH < g.ci) fetch(c0 + KCH);   // in flight during the multiply phase
@@ -264,6 +314,7 @@ bool conv_up2_eligible(const sg_conv2d_params& p) {
     if (p.out_scale || p.bias || p.noise || p.reduce_out || p.act != 1 || p.gain != 1.f || p.clamp >= 0.f) return false;
     if (p.w_in % 8 != 0 || p.ow % 8 != 0 || p.ci % 8 != 0 || p.w_in < 16 || p.ci < KCH) return false;
     if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.y)) return false;
+    if ((int64_t)p.ci * p.h * p.w_in >= (int64_t)1 << 30 || (int64_t)p.co * p.ci >= (1 << 26)) return false;   // buffer offsets < 2^31 bytes
     return true;
 }
 
@@ -282,13 +333,19 @@ int conv_up2_launch(const sg_conv2d_params& p, hipStream_t stream) {
     g.units = (int)units;
     const size_t lds = kInBytes + kWBytes * (wide ? 2 : 1);   // 59904 at most: below the 64 KB that need no opt-in
     const dim3 grid((unsigned)((units + 7) / 8 * 8));
+    g.w_bytes = (unsigned)(9u * (unsigned)p.co * (unsigned)p.ci * 2u);
+    const bool mod = p.in_scale != nullptr;
+#define SG_UP2_LAUNCH(T, WAVES)                                                                                         \
+    do {                                                                                                                \
+        if (mod) hipLaunchKernelGGL((conv_up2_kernel<T, WAVES, true>), grid, dim3(64 * WAVES), lds, stream, g);         \
+        else hipLaunchKernelGGL((conv_up2_kernel<T, WAVES, false>), grid, dim3(64 * WAVES), lds, stream, g);            \
+    } while (0)
     if (p.dtype == SG_BF16) {
-        if (wide) hipLaunchKernelGGL((conv_up2_kernel<__hip_bfloat16, 8>), grid, dim3(512), lds, stream, g);
-        else hipLaunchKernelGGL((conv_up2_kernel<__hip_bfloat16, 4>), grid, dim3(256), lds, stream, g);
+        if (wide) SG_UP2_LAUNCH(__hip_bfloat16, 8); else SG_UP2_LAUNCH(__hip_bfloat16, 4);
     } else {
-        if (wide) hipLaunchKernelGGL((conv_up2_kernel<__half, 8>), grid, dim3(512), lds, stream, g);
-        else hipLaunchKernelGGL((conv_up2_kernel<__half, 4>), grid, dim3(256), lds, stream, g);
+        if (wide) SG_UP2_LAUNCH(__half, 8); else SG_UP2_LAUNCH(__half, 4);
     }
+#undef SG_UP2_LAUNCH
     return check_launch("sg_conv2d");
 }
 
