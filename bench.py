@@ -225,12 +225,30 @@ def cpu_baseline():
                        % (timed, cores, times['Gmain'], times['Dmain'], times['Greg'], times['Dreg'], gmain_1t))
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT the HIP runtime (the parent must stay free of it: it starts the
+    ranks): the nodes of the kernel driver's topology that have SIMDs, narrowed by the *_VISIBLE_DEVICES lists."""
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if os.environ.get(var) is not None:
+            return len([d for d in os.environ[var].split(',') if d.strip() != ''])
+    count = 0
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get('simd_count', 0)) > 0:
+                count += 1
+    except OSError:
+        return None            # no topology to read: let the ranks find out
+    return count
+
+
 def launch_ranks(args):
-    """`--gpus N` without a launcher: start one rank per GPU from this process, which has not touched the GPU
-    (counting devices does not initialise it), wait for all of them, exit with the first failure."""
-    import torch.cuda
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+    """`--gpus N` without a launcher: start one rank per GPU from this process, which never touches the HIP
+    runtime (every rank checks for itself that its GPU exists), wait for all of them, exit with the first failure."""
+    have = visible_gpus()
+    if have is not None and have < args.gpus:
         raise SystemExit(f'bench.py --gpus {args.gpus} needs {args.gpus} GPUs: {have} visible')
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))

@@ -17,7 +17,7 @@ SYMBOLS = ('sg_version', 'sg_last_error', 'sg_init', 'sg_upfirdn2d_out_size', 's
            'sg_epilogue_backward', 'sg_conv2d_reduce_rows', 'sg_conv2d_kernel', 'sg_conv2d_wgrad_kernel',
            'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask',
            'sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes', 'sg_conv_up2_fir', 'sg_conv_up2_fir_supported',
-           'sg_upfirdn2d_add', 'sg_upfirdn2d_add_supported', 'sg_planes_segments', 'sg_scale_planes', 'sg_dot_planes')
+           'sg_upfirdn2d_add', 'sg_upfirdn2d_add_supported', 'sg_upfirdn2d_kernel', 'sg_planes_segments', 'sg_scale_planes', 'sg_dot_planes')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -75,6 +75,8 @@ def lib():
         handle.sg_upfirdn2d_add.restype = ctypes.c_int
         handle.sg_upfirdn2d_add_supported.argtypes = [ctypes.POINTER(Upfirdn2dParams)]
         handle.sg_upfirdn2d_add_supported.restype = ctypes.c_int
+        handle.sg_upfirdn2d_kernel.argtypes = [ctypes.POINTER(Upfirdn2dParams), vp]
+        handle.sg_upfirdn2d_kernel.restype = ctypes.c_char_p
         handle.sg_planes_segments.argtypes = [ctypes.c_int, i64]
         handle.sg_planes_segments.restype = ctypes.c_int
         handle.sg_scale_planes.argtypes = [vp, vp, vp, ctypes.c_int, i64, i64, vp]

@@ -123,12 +123,6 @@ struct BandArgs {
 // the 128-byte window of an 8-byte store: the 16 lanes of a store group (8 channel groups x 2 rows) never collide.
 __device__ __forceinline__ int img_off(int r, int c, int s) { return (r * IW + c) * kPix + (((s ^ (c >> 2)) & 3) << 4); }
 
-#ifdef BAND_ABL_STAMPS
-__device__ unsigned long long band_stamps[8][8][8];   // [wave][step 4..11][point]
-#define STAMP(q, k) do { if (blockIdx.x == 0 && item == (int)(blockIdx.x >> 3) && (q) >= 4 && (q) < 12 && lane == 0) band_stamps[wave][(q) - 4][k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP(q, k) do {} while (0)
-#endif
 
 template <bool MASK> struct Staged {   // the packets of one staging unit (and of its mask), and a piece of the noise tile
     uint4 p[4];
@@ -228,10 +222,6 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
             const unsigned off = ok ? ((unsigned)(4 * u_c4) * uplane + (unsigned)(yy * g.wid + col)) * 2u : kOutside;   // bytes
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-#ifdef BAND_ABL_NOLOAD
-                st.p[e] = make_uint4(q, e, tid, 1);
-                continue;
-#endif
                 st.p[e] = load16(xr, off, e * uplane * 2u);
                 if constexpr (MASK) st.m[e] = load16(mr, off, e * uplane * 2u);
             }
@@ -267,11 +257,7 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
                 uint2 o;
                 o.x = __builtin_amdgcn_perm(wd[1][j >> 1], wd[0][j >> 1], sel);   // channels 4 c4, 4 c4 + 1 of pixel j
                 o.y = __builtin_amdgcn_perm(wd[3][j >> 1], wd[2][j >> 1], sel);
-#ifdef BAND_ABL_NOCOMMIT
-                asm volatile("" :: "v"(o.x), "v"(o.y));
-#else
                 *reinterpret_cast<uint2*>(img + img_off(u_r, CARRY + 8 * u_v + j, u_c4 >> 1) + 8 * (u_c4 & 1)) = o;
-#endif
             }
             if (q >= 1 && tid < IH * CARRY * 4) {   // the 9 right-most columns of the previous image
                 const unsigned char* prev = s_img + ((q - 1) & 1) * kImg;
@@ -321,11 +307,7 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
 #pragma unroll
                     for (int ky = 0; ky < 3; ky++) {
                         const int o = ir - ky;
-#ifdef BAND_ABL_NOMFMA
-                        if (o == 0 || o == 1) { acc[o][0] += __builtin_bit_cast(float, fa[idx & 1][ks].x ^ wreg[ky * 3 + kx][ks].y); }
-#else
                         if (o == 0 || o == 1) Mma32<T>::run(fa[idx & 1][ks], wreg[ky * 3 + kx][ks], acc[o]);
-#endif
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -354,9 +336,6 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
                     }
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-#ifdef BAND_ABL_NOEPI
-                        continue;
-#endif
                         float z = __builtin_fmaf(v[e], scg, __builtin_fmaf(nzv[e], ngg, bsg));
                         z = __builtin_fmaxf(z, z * g.slope);
                         v[e] = __builtin_amdgcn_fmed3f(z, -g.hi, g.hi);
@@ -374,11 +353,7 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
                 const uint4 out = *reinterpret_cast<const uint4*>(s_out + run * kOutRow + 16 * piece);
                 const int row = y0 + 2 * rg + o, col = (t - 1) * TWX + 32 * sx + 8 * piece;
                 const bool ok = row < g.h && col >= 0 && col < g.wid;
-#ifdef BAND_ABL_NOSTORE
-                asm volatile("" :: "v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
-#else
                 store16(yr, ok ? ((unsigned)(cog * 32 + ch) * uplane + (unsigned)(row * g.wid + col)) * 2u : kOutside, out);
-#endif
             }
         };
 
@@ -393,22 +368,15 @@ __global__ void __launch_bounds__(kThreads, 2) band3x3_kernel(BandArgs g) {
 
         // step q: `mine` held image q (committed, free again), `other` holds image q + 1 when loads run two steps ahead
         auto step = [&](int q, Staged<MASK>& mine, Staged<MASK>& other) {
-            STAMP(q, 0);
             if (q + DEPTH < Q) issue(q + DEPTH, mine);
-            STAMP(q, 1);
             if (late && q > 0 && active(q - 1)) epilogue(q - 1);
-            STAMP(q, 2);
             if (active(q)) {
                 load_rx(q);
                 multiply(q);
-                STAMP(q, 3);
                 if (!late) epilogue(q);
             }
-            STAMP(q, 4);
             if (q + 1 < Q) commit(q + 1, DEPTH == 2 ? other : mine);
-            STAMP(q, 5);
             __syncthreads();
-            STAMP(q, 6);
         };
         for (int q = 0; q < Q; q += 2) {
             step(q, s0, s1);
@@ -491,8 +459,3 @@ int band3x3_launch(const sg_conv2d_params& p, hipStream_t stream) {
 
 }  // namespace sg
 
-#ifdef BAND_ABL_STAMPS
-extern "C" int sg_debug_band_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sg::band_stamps), sizeof(unsigned long long) * 512);
-}
-#endif

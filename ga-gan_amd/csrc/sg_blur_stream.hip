@@ -572,9 +572,6 @@ int launch_stream_pad(const sg_upfirdn2d_params& p, const sg_epilogue* ep, hipSt
 }  // namespace
 
 bool blur_stream_eligible(const sg_upfirdn2d_params& p, const sg_epilogue* ep) {
-#ifdef BAND_ABL_NOSTREAM
-    return false;
-#endif
     if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
     if (p.up_x != 1 || p.up_y != 1 || p.down_x != 1 || p.down_y != 1 || p.f_w > 4 || p.f_h > 4) return false;
     if (p.in_stride_w != 1 || p.out_stride_w != 1 || p.pad_x0 < 0 || p.pad_x0 > 3) return false;

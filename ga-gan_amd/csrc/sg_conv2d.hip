@@ -447,10 +447,8 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             w_load(wreg_a, cb, g0);
             x_load(cb);
             w_load(wreg_b, cb1, g1);
-#ifndef BAND_ABL_NOSTAGE
             x_commit(s_x[cb & 1], cb);
             w_commit(wreg_a, s_wb[0], g0);
-#endif
             __syncthreads();
         }
         // On entry the LDS buffer sidx & 1 holds this stage's weights, `next` holds (or awaits) those of the stage
@@ -459,10 +457,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             const bool first = g0 == 0, last = cb1 != cb;
             w_load(far, cb2, g2);
             if (first && cb + 1 < cb_end) x_load(cb + 1);
-#ifndef BAND_ABL_NOCOMPUTE
             split_multiply(s_wb[sidx & 1], s_x[cb & 1], g0, min(kSplitTaps, taps - g0));
-#endif
-#ifndef BAND_ABL_NOSTAGE
             if (cb1 < cb_end) {
                 w_commit(next, s_wb[(sidx + 1) & 1], g1);
                 if (last) {
@@ -470,7 +465,6 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
                     x_commit(s_x[cb1 & 1], cb1);
                 }
             }
-#endif
             __syncthreads();
             cb = cb1; g0 = g1;
             cb1 = cb2; g1 = g2;

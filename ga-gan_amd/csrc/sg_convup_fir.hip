@@ -114,12 +114,6 @@ struct Stage {                                        // what a step's loads lea
 
 // RESIDENT: at most 64 input and 32 output channels - the two weight buffers hold the whole composed kernel and are
 // filled once per workgroup; otherwise the weights of the next chunk are fetched during every multiply phase.
-#ifdef BAND_ABL_STAMPS
-__device__ unsigned long long up_stamps[8][16][8];   // [wave][step 4..19][point]
-#define STAMP(k) do { if (blockIdx.x == 0 && nstep >= 4 && nstep < 20 && lane == 0) up_stamps[wave][nstep - 4][k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
 
 template <class T, bool RESIDENT>
 __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) {
@@ -191,10 +185,6 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
             const int iy = t.a0 - 1 + ry, px0 = t.b0 - 8 + col;
             st.va[q] = make_uint4(0, 0, 0, 0);
             st.vb[q] = make_uint4(0, 0, 0, 0);
-#ifdef BAND_ABL_NOLOAD
-            st.va[q] = make_uint4(ry, q, tid, 1);
-            continue;
-#endif
             if (c_ok && live && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
                 const T* src = src0 + iy * g.wid + px0;
                 st.va[q] = *reinterpret_cast<const uint4*>(src);
@@ -272,11 +262,7 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
                 unsigned out;
                 if (scale) out = Pair<T>::pack(Pair<T>::lo(ea) * st.s0, Pair<T>::lo(eb) * st.s1);
                 else out = (ea & 0xffffu) | (eb << 16);
-#ifdef BAND_ABL_NOCOMMIT
-                asm volatile("" :: "v"(out));
-#else
                 *reinterpret_cast<unsigned*>(img + swz(r0 + j, cg * 4)) = out;
-#endif
             };
             if (!halo) {
 #pragma unroll
@@ -321,11 +307,7 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
                     const int py = rt == 2 ? 1 : 0, dy = rt == 1 ? -1 : 0;
                     const uint4 fa = *reinterpret_cast<const uint4*>(wts + combo * BCO * kRow);
 #pragma unroll
-#ifdef BAND_ABL_NOMFMA
-                    for (int r = 1 - py; r < LH; r++) acc[r][py][px][0] += __builtin_bit_cast(float, fp[r + dy].x ^ fa.y);
-#else
                     for (int r = 1 - py; r < LH; r++) Mma16<T>::run(fp[r + dy], fa, acc[r][py][px]);
-#endif
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -379,11 +361,7 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
                 unsigned words[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) words[e] = Pair<T>::pack(z[0][e >> 1][e & 1], z[1][e >> 1][e & 1]);
-#ifdef BAND_ABL_NOSTORE
-                asm volatile("" :: "v"(words[0]), "v"(words[1]), "v"(words[2]), "v"(words[3]));
-#else
                 *reinterpret_cast<uint4*>(dst0 + (int64_t)(oy0 + py) * ow) = make_uint4(words[0], words[1], words[2], words[3]);
-#endif
             }
         }
     };
@@ -425,29 +403,23 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
     // `mine` held this step's packets (committed: free again), `other` holds the next step's
     [[maybe_unused]] int nstep = 0;
     auto step = [&](Stage& mine, Stage& other) __attribute__((always_inline)) {
-        STAMP(0);
         if (p2.ok) issue(p2, mine);
         if constexpr (!RESIDENT) {
             if (p1.ok) load_weights(p1.t.m0, p1.c * KCH, -1, vw);
         }
         // late waves: the previous tile's filter / epilogue / stores first, then multiply; early waves: multiply, then
         // (after a tile's last chunk) filter / epilogue / stores
-        STAMP(1);
         if (pending) { finish(done, done_idx, scg, bsg); clear(); pending = false; }
         if (p0.c == 0) { scg = nscg; bsg = nbsg; }
-        STAMP(2);
         multiply(buf, RESIDENT ? p0.c : buf);
-        STAMP(3);
         if (p0.c + 1 == chunks) {
             if (late) { pending = true; done = p0.t; done_idx = p0.idx; }
             else { finish(p0.t, p0.idx, scg, bsg); clear(); }
         }
-        STAMP(4);
         if (p1.ok) {
             commit(p1, other, buf ^ 1);
             if constexpr (!RESIDENT) store_weights(buf ^ 1, vw);
         }
-        STAMP(5);
         __syncthreads();
         if constexpr (RESIDENT) {
             if (g.in_scale && p1.ok && p1.c == 0 && p1.t.n != p0.t.n) {   // (uniform) the next tile is another sample's
@@ -455,7 +427,6 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
                 __syncthreads();
             }
         }
-        STAMP(6);
         nstep++;
         buf ^= 1;
         p0 = p1; p1 = p2; p2 = advance(p2);
@@ -535,8 +506,3 @@ extern "C" int sg_conv_up2_fir(const sg_conv_up2_fir_params* p, sg_stream_t stre
     return launch_up_fir<__half>(g, (hipStream_t)stream);
 }
 
-#ifdef BAND_ABL_STAMPS
-extern "C" int sg_debug_up_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sg::up_stamps), sizeof(unsigned long long) * 8 * 16 * 8);
-}
-#endif

@@ -453,6 +453,26 @@ extern "C" int sg_upfirdn2d(const sg_upfirdn2d_params* p, sg_stream_t stream) {
     return SG_OK;
 }
 
+extern "C" const char* sg_upfirdn2d_kernel(const sg_upfirdn2d_params* p, const sg_epilogue* ep) {
+    // mirrors launch() / launch_blur4() above
+    using namespace sg;
+    if (p == nullptr) return "";
+    if (p->dtype == SG_F64) return "upfirdn2d_generic_kernel";
+    const bool rows_contiguous = p->in_stride_w == 1 && p->out_stride_w == 1;
+    const int ux = p->up_x, uy = p->up_y, dx = p->down_x, dy = p->down_y;
+    if (rows_contiguous && p->f_w <= 4 && p->f_h <= 4) {
+        if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return blur_stream_eligible(*p, ep) ? "blur4_stream_kernel" : "upfirdn2d_blur4_kernel";
+        if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return up2_stream_eligible(*p) ? "up2_stream_kernel" : "upfirdn2d_tiled_kernel";
+        if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return down2_stream_eligible(*p) ? "down2_stream_kernel" : "upfirdn2d_tiled_kernel";
+    }
+    if (ep != nullptr) return "";
+    if (rows_contiguous && p->f_w <= 12 && p->f_h == 1 && uy == 1 && dy == 1 && ((ux == 2 && dx == 1) || (ux == 1 && dx == 2)))
+        return "upfirdn2d_tiled_kernel";
+    if (rows_contiguous && p->f_h <= 12 && p->f_w == 1 && ux == 1 && dx == 1 && ((uy == 2 && dy == 1) || (uy == 1 && dy == 2)))
+        return "upfirdn2d_tiled_kernel";
+    return "upfirdn2d_generic_kernel";
+}
+
 extern "C" int sg_upfirdn2d_add_supported(const sg_upfirdn2d_params* p) {
     return (p != nullptr && p->in_c > 0 && p->in_n > 0 && p->out_w >= 1 && p->out_h >= 1 && sg::up2_stream_eligible(*p)) ? 1 : 0;
 }

@@ -37,10 +37,6 @@ constexpr int BC = 64;             // channels of either operand per workgroup
 constexpr int kRowBytes = 288;     // bytes per LDS pixel row
 constexpr int kMaxPixelRows = 560; // x footprint + g tile, in pixel rows: 157.5 KB
 
-#ifdef BAND_ABL_STAMPS
-__device__ unsigned long long wgrad_stamps[4][16];   // [wave][phase sums: stage, barrier, compute, tiles, epilogue]
-#define WSTAMP() __builtin_amdgcn_s_memtime()
-#endif
 
 struct WTile {
     int tw, th, imgs;             // gradient pixels per tile: tw (8, 16 or 32) x th (a multiple of 32 / tw) x imgs
@@ -166,33 +162,18 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
     stage_x.setup(xs, chunks_x, cx0 / 32, p.n, p.h, p.w_in, t.imgs, t.lh, t.lw);
     stage_g.setup(gs, chunks_g, cg0 / 32, p.n, p.gh, p.gw, t.imgs, t.th, t.tw);
 
-#ifdef BAND_ABL_STAMPS
-    unsigned long long t_stage = 0, t_bar = 0, t_comp = 0, n_tiles = 0, t_begin = WSTAMP();
-#endif
     for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
-#ifdef BAND_ABL_STAMPS
-        const unsigned long long s0 = WSTAMP();
-#endif
         int rest = tile;
         const int tb = rest % t.tiles_b; rest /= t.tiles_b;
         const int ta = rest % t.tiles_a; rest /= t.tiles_a;
         const int img0 = rest * t.imgs;
         const int a0 = ta * t.th, b0 = tb * t.tw;
         __syncthreads();
-#ifndef BAND_ABL_NOSTAGE
         stage_x.load(img0, a0 * p.step + p.dy0, b0 * p.step + p.dx0);
         stage_g.load(img0, a0, b0);
         stage_x.store(s_x);
         stage_g.store(s_g);
-#endif
-#ifdef BAND_ABL_STAMPS
-        const unsigned long long s1 = WSTAMP();
-#endif
         __syncthreads();
-#ifdef BAND_ABL_STAMPS
-        const unsigned long long s2 = WSTAMP();
-#endif
-#ifndef BAND_ABL_NOCOMPUTE
 
         for (int ri = 0; ri < t.imgs; ri++) {
             for (int ra = 0; ra < t.th; ra += rows_per_step) {
@@ -237,15 +218,7 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
                 }
             }
         }
-#endif
-#ifdef BAND_ABL_STAMPS
-        const unsigned long long s3 = WSTAMP();
-        t_stage += s1 - s0; t_bar += s2 - s1; t_comp += s3 - s2; n_tiles++;
-#endif
     }
-#ifdef BAND_ABL_STAMPS
-    const unsigned long long t_loop = WSTAMP();
-#endif
 
     // ---- add into dw[tap][cg][cx]: lanes of a row run along cx ------------------------------------------------
     float* __restrict__ dw = p.dw;
@@ -261,12 +234,6 @@ __global__ void __launch_bounds__(kThreads, 1) wgrad_f32_kernel(sg_conv2d_wgrad_
                     const int cx = cx0 + (wave & 1) * 32 + n * 16 + lrow;
                     if (cg < p.cg && cx < p.cx) atomicAdd(dw + ((int64_t)tp * p.cg + cg) * p.cx + cx, acc[tp][m][n][r] * inv_x * inv_g);
                 }
-#ifdef BAND_ABL_STAMPS
-    if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 1 && lane == 0) {
-        unsigned long long* o = wgrad_stamps[wave];
-        o[0] = t_stage; o[1] = t_bar; o[2] = t_comp; o[3] = n_tiles; o[4] = WSTAMP() - t_loop; o[5] = t_loop - t_begin;
-    }
-#endif
 }
 
 WTile make_wtile(const sg_conv2d_wgrad_params& p) {
@@ -332,8 +299,3 @@ int wgrad_f32_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
 
 }  // namespace sg
 
-#ifdef BAND_ABL_STAMPS
-extern "C" int sg_debug_wgrad_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sg::wgrad_stamps), sizeof(unsigned long long) * 64);
-}
-#endif

@@ -66,8 +66,9 @@ def blur_epilogue(x, f, padding, flip, filter_gain, **epilogue):
         in_stride_w=x.stride(3), in_stride_h=x.stride(2), in_stride_c=x.stride(1), in_stride_n=x.stride(0),
         f_w=f.shape[1], f_h=f.shape[0], f_stride_w=f.stride(1), f_stride_h=f.stride(0), out_w=ow, out_h=oh,
         out_stride_w=y.stride(3), out_stride_h=y.stride(2), out_stride_c=y.stride(1), out_stride_n=y.stride(0))
+    label = _lib.lib().sg_upfirdn2d_kernel(ctypes.byref(p), ctypes.byref(ep)).decode() if _lib.profiling() else ''
     _lib.launch_raw(lambda stream: _lib.lib().sg_upfirdn2d_epilogue(ctypes.byref(p), ctypes.byref(ep), stream), x,
-                    'sg_upfirdn2d_epilogue', 'upfirdn2d_blur4_kernel', _lib.nbytes(x, y))
+                    'sg_upfirdn2d_epilogue', label, _lib.nbytes(x, y))
     return y
 
 

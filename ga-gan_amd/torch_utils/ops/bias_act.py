@@ -81,7 +81,7 @@ class _BiasAct(torch.autograd.Function):
                 dx = _BiasActGrad.apply(dy, x, b, y, ctx.cfg)
         # (inside conv2d_gradfix.no_weight_gradients() - the first-order passes of the two regularisers, which ask for the
         # gradient of an activation only - the bias gradient is a reduction over the whole tensor that nobody reads)
-        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.parameter_gradients_disabled:
             db = _sum_except(dx, dim)
         return dx, db, None
 

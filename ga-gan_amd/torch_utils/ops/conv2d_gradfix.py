@@ -21,15 +21,23 @@ enabled = True                      # kept for callers that set it (training_loo
 weight_gradients_disabled = False   # True inside no_weight_gradients()
 
 
+parameter_gradients_disabled = False   # True inside no_weight_gradients(all_parameters=True)
+
+
 @contextlib.contextmanager
-def no_weight_gradients():
-    global weight_gradients_disabled
-    old = weight_gradients_disabled
+def no_weight_gradients(all_parameters=False):
+    """Inside, convolutions return no weight gradient (reference: conv2d_gradfix.py:26-32).  With
+    `all_parameters=True` the bias gradient of `bias_act` and the addend gradient of `fma` (whole-tensor reductions)
+    are skipped as well: for callers that differentiate with respect to inputs only, as the loss's two
+    regularisers do.  Without it those two ops behave as the reference's do inside this context."""
+    global weight_gradients_disabled, parameter_gradients_disabled
+    old = weight_gradients_disabled, parameter_gradients_disabled
     weight_gradients_disabled = True
+    parameter_gradients_disabled = parameter_gradients_disabled or all_parameters
     try:
         yield
     finally:
-        weight_gradients_disabled = old
+        weight_gradients_disabled, parameter_gradients_disabled = old
 
 
 def _pair(v):

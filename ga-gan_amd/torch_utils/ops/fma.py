@@ -34,5 +34,5 @@ class _Fma(torch.autograd.Function):
         db = _reduce_to(dout * a, b.shape) if ctx.needs_input_grad[1] else None
         # c is the noise term of a synthesis layer (noise buffer x learned strength): like a weight gradient, its gradient
         # is not wanted inside conv2d_gradfix.no_weight_gradients()
-        dc = _reduce_to(dout, ctx.c_shape) if ctx.needs_input_grad[2] and not conv2d_gradfix.weight_gradients_disabled else None
+        dc = _reduce_to(dout, ctx.c_shape) if ctx.needs_input_grad[2] and not conv2d_gradfix.parameter_gradients_disabled else None
         return da, db, dc

@@ -76,7 +76,8 @@ def _one_pass_up(x, w, f, k, blur_pad, extra, act, alpha, gain):
     if taps is None:
         return None
     m, fy4 = taps
-    return memo.memo(w, 'up2_fir', lambda: _layer.compose_up2_weights(w, m)), fy4
+    # (keyed by the filter's identity and version as well: the composed weights hold its horizontal taps)
+    return memo.memo(w, ('up2_fir', f.data_ptr(), f._version), lambda: _layer.compose_up2_weights(w, m)), fy4
 
 
 _twice = False   # True inside differentiable_twice()

@@ -91,107 +91,136 @@ class StyleGAN2Loss(Loss):
             img = self.augment_pipe(img)
         return self.D(img, c)
 
+    # ---- building blocks of the phases ------------------------------------------------------------------------
+    # Every phase is: a forward pass inside a '<term>_forward' profiler scope that ends in a per-sample loss, then one
+    # backward call of mean(loss) * gain inside '<term>_backward'.  The reducer is armed in front of the backward call
+    # that completes the phase's gradients, and only there.
+
+    @staticmethod
+    def _scope(term, part):
+        return torch.autograd.profiler.record_function(f'{term}_{part}')
+
+    @staticmethod
+    def _report_scores(kind, logits):
+        training_stats.report(f'Loss/scores/{kind}', logits)
+        training_stats.report(f'Loss/signs/{kind}', logits.sign())
+
+    def _backward(self, term, per_sample, gain, final, anchor=None):
+        """mean(per_sample) * gain -> gradients.  `anchor` (a tensor of the forward pass, one element per sample) is
+        added with weight zero: every parameter behind it then receives a gradient tensor - zeros where the loss
+        does not reach it - which is what the reference's `x * 0 + loss` idiom (loss.py:111, :152) produces, and
+        what decides which parameters the optimizer steps."""
+        with self._scope(term, 'backward'):
+            if final:
+                self._arm(True)
+            if anchor is not None:
+                per_sample = anchor * 0 + per_sample
+            per_sample.mean().mul(gain).backward()
+
+    def _g_main(self, gen_z, gen_c, gain, final):
+        """Generator: non-saturating loss softplus(-D(G(z)))  (reference loss.py:77-86)."""
+        with self._scope('Gmain', 'forward'):
+            fake, _ = self.run_G(gen_z, gen_c, sync=final)
+            logits = self.run_D(fake, gen_c, sync=False)
+            self._report_scores('fake', logits)
+            loss = torch.nn.functional.softplus(-logits)
+            training_stats.report('Loss/G/loss', loss)
+        self._backward('Gmain', loss, gain, final)
+
+    def _g_path_length(self, gen_z, gen_c, gain, final, noise_unit):
+        """Generator: path-length penalty on the first batch / pl_batch_shrink samples  (reference loss.py:89-111)."""
+        with self._scope('Gpl', 'forward'):
+            count = gen_z.shape[0] // self.pl_batch_shrink
+            with fused_layer.differentiable_twice():
+                fake, ws = self.run_G(gen_z[:count], gen_c[:count], sync=final, set_w_requires_grad=True)
+            direction = (torch.randn_like(fake) if noise_unit is None else noise_unit) / np.sqrt(fake.shape[2] * fake.shape[3])
+            with torch.autograd.profiler.record_function('pl_grads'), conv2d_gradfix.no_weight_gradients(all_parameters=True):
+                jvp, = torch.autograd.grad(outputs=[(fake * direction).sum()], inputs=[ws], create_graph=True,
+                                           only_inputs=True, allow_unused=True)
+            lengths = jvp.square().sum(2).mean(1).sqrt()
+            mean = self.pl_mean.lerp(lengths.mean(), self.pl_decay)
+            self.pl_mean.copy_(mean.detach())
+            penalty = (lengths - mean).square()
+            training_stats.report('Loss/pl_penalty', penalty)
+            loss = penalty * self.pl_weight
+            training_stats.report('Loss/G/reg', loss)
+        self._backward('Gpl', loss, gain, final, anchor=fake[:, 0, 0, 0])
+
+    def _d_main_merged(self, groups, real_img, real_c, gen_z, gen_c, gain, final):
+        """Discriminator: softplus(D(G(z))) + softplus(-D(real)) from ONE pass over both halves (see _merged_groups)."""
+        with self._scope('Dmain', 'forward'):
+            fake, _ = self.run_G(gen_z, gen_c, sync=False)
+            real = real_img.detach()
+            if self.augment_pipe is not None:
+                fake, real = self.augment_pipe(fake), self.augment_pipe(real)
+            logits = self.D(_interleave(fake, real, groups), _interleave(gen_c, real_c, groups))
+            runs = logits.unflatten(0, (groups, logits.shape[0] // groups))      # [group row, fake run | real run, 1]
+            half = runs.shape[1] // 2
+            fake_logits, real_logits = runs[:, :half].flatten(0, 1), runs[:, half:].flatten(0, 1)
+            self._report_scores('fake', fake_logits)
+            self._report_scores('real', real_logits)
+            loss_fake = torch.nn.functional.softplus(fake_logits)
+            loss_real = torch.nn.functional.softplus(-real_logits)
+            training_stats.report('Loss/D/loss', loss_fake + loss_real)
+        with self._scope('Dmain', 'backward'):
+            if final:
+                self._arm(True)
+            (loss_fake.mean() + loss_real.mean()).mul(gain).backward()
+
+    def _d_fake(self, gen_z, gen_c, gain):
+        """Discriminator on generated images: softplus(D(G(z)))  (reference loss.py:115-123).  Never the last
+        backward call of its phase: the real half follows."""
+        with self._scope('Dgen', 'forward'):
+            fake, _ = self.run_G(gen_z, gen_c, sync=False)
+            logits = self.run_D(fake, gen_c, sync=False)
+            self._report_scores('fake', logits)
+            loss = torch.nn.functional.softplus(logits)
+        self._backward('Dgen', loss, gain, final=False)
+        return loss
+
+    def _d_real(self, real_img, real_c, gain, final, with_main, with_r1, loss_fake):
+        """Discriminator on real images: softplus(-D(x)) and / or the R1 penalty gamma / 2 * |dD/dx|^2
+        (reference loss.py:127-152)."""
+        term = 'Dreal_Dr1' if with_main and with_r1 else 'Dreal' if with_main else 'Dr1'
+        with self._scope(term, 'forward'):
+            x = real_img.detach().requires_grad_(with_r1)
+            with fused_layer.differentiable_twice() if with_r1 else contextlib.nullcontext():
+                logits = self.run_D(x, real_c, sync=final)
+            self._report_scores('real', logits)
+            total = 0
+            if with_main:
+                main = torch.nn.functional.softplus(-logits)
+                training_stats.report('Loss/D/loss', loss_fake + main)
+                total = total + main
+            if with_r1:
+                with torch.autograd.profiler.record_function('r1_grads'), conv2d_gradfix.no_weight_gradients(all_parameters=True):
+                    slope, = torch.autograd.grad(outputs=[logits.sum()], inputs=[x], create_graph=True, only_inputs=True)
+                penalty = slope.square().sum([1, 2, 3])
+                reg = penalty * (self.r1_gamma / 2)
+                training_stats.report('Loss/r1_penalty', penalty)
+                training_stats.report('Loss/D/reg', reg)
+                total = total + reg
+        self._backward(term, total, gain, final, anchor=logits)
+
     def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain, pl_noise_unit=None):
-        assert phase in ['Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth']
-        do_Gmain = (phase in ['Gmain', 'Gboth'])
-        do_Dmain = (phase in ['Dmain', 'Dboth'])
-        do_Gpl = (phase in ['Greg', 'Gboth']) and (self.pl_weight != 0)
-        do_Dr1 = (phase in ['Dreg', 'Dboth']) and (self.r1_gamma != 0)
+        """Gradients of one phase into the .grad of the parameters that require them.  `sync`: this is the last
+        accumulation round of the phase, i.e. the gradients are final after it."""
+        if phase not in ('Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth'):
+            raise ValueError(f'unknown phase {phase!r}')
+        g_main = phase in ('Gmain', 'Gboth')
+        g_reg = phase in ('Greg', 'Gboth') and self.pl_weight != 0
+        d_main = phase in ('Dmain', 'Dboth')
+        d_reg = phase in ('Dreg', 'Dboth') and self.r1_gamma != 0
 
-        # Gmain: maximise logits of generated images.
-        if do_Gmain:
-            with torch.autograd.profiler.record_function('Gmain_forward'):
-                gen_img, _ = self.run_G(gen_z, gen_c, sync=(sync and not do_Gpl))
-                gen_logits = self.run_D(gen_img, gen_c, sync=False)
-                training_stats.report('Loss/scores/fake', gen_logits)
-                training_stats.report('Loss/signs/fake', gen_logits.sign())
-                loss_Gmain = torch.nn.functional.softplus(-gen_logits)
-                training_stats.report('Loss/G/loss', loss_Gmain)
-            with torch.autograd.profiler.record_function('Gmain_backward'):
-                self._arm(sync and not do_Gpl)   # (Gboth: the path-length pass adds to the same gradients)
-                loss_Gmain.mean().mul(gain).backward()
-
-        # Gpl: path-length regularisation on a shrunk batch.
-        if do_Gpl:
-            with torch.autograd.profiler.record_function('Gpl_forward'):
-                batch_size = gen_z.shape[0] // self.pl_batch_shrink
-                with fused_layer.differentiable_twice():
-                    gen_img, gen_ws = self.run_G(gen_z[:batch_size], gen_c[:batch_size], sync=sync, set_w_requires_grad=True)
-                unit = torch.randn_like(gen_img) if pl_noise_unit is None else pl_noise_unit
-                pl_noise = unit / np.sqrt(gen_img.shape[2] * gen_img.shape[3])
-                with torch.autograd.profiler.record_function('pl_grads'), conv2d_gradfix.no_weight_gradients():
-                    pl_grads = torch.autograd.grad(outputs=[(gen_img * pl_noise).sum()], inputs=[gen_ws],
-                                                   create_graph=True, only_inputs=True, allow_unused=True)[0]
-                pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
-                pl_mean = self.pl_mean.lerp(pl_lengths.mean(), self.pl_decay)
-                self.pl_mean.copy_(pl_mean.detach())
-                pl_penalty = (pl_lengths - pl_mean).square()
-                training_stats.report('Loss/pl_penalty', pl_penalty)
-                loss_Gpl = pl_penalty * self.pl_weight
-                training_stats.report('Loss/G/reg', loss_Gpl)
-            with torch.autograd.profiler.record_function('Gpl_backward'):
-                self._arm(sync)
-                (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
-
-        # Dmain, both halves in one discriminator pass where that is the same computation.
-        groups = self._merged_groups(gen_z.shape[0], real_img.shape[0]) if do_Dmain and not do_Dr1 else None
-        if groups is not None:
-            with torch.autograd.profiler.record_function('Dmain_forward'):
-                gen_img, _ = self.run_G(gen_z, gen_c, sync=False)
-                if self.augment_pipe is not None:
-                    gen_img, real_aug = self.augment_pipe(gen_img), self.augment_pipe(real_img.detach())
-                else:
-                    real_aug = real_img.detach()
-                logits = self.D(_interleave(gen_img, real_aug, groups), _interleave(gen_c, real_c, groups))
-                per_group = logits.unflatten(0, (groups, logits.shape[0] // groups))
-                half = per_group.shape[1] // 2
-                gen_logits, real_logits = per_group[:, :half].flatten(0, 1), per_group[:, half:].flatten(0, 1)
-                training_stats.report('Loss/scores/fake', gen_logits)
-                training_stats.report('Loss/signs/fake', gen_logits.sign())
-                training_stats.report('Loss/scores/real', real_logits)
-                training_stats.report('Loss/signs/real', real_logits.sign())
-                loss_Dgen = torch.nn.functional.softplus(gen_logits)
-                loss_Dreal = torch.nn.functional.softplus(-real_logits)
-                training_stats.report('Loss/D/loss', loss_Dgen + loss_Dreal)
-            with torch.autograd.profiler.record_function('Dmain_backward'):
-                self._arm(sync)
-                (loss_Dgen.mean() + loss_Dreal.mean()).mul(gain).backward()
+        if g_main:
+            self._g_main(gen_z, gen_c, gain, final=sync and not g_reg)   # (Gboth: the path-length pass adds to the same gradients)
+        if g_reg:
+            self._g_path_length(gen_z, gen_c, gain, final=sync, noise_unit=pl_noise_unit)
+        if not (d_main or d_reg):
             return
-
-        # Dmain: minimise logits of generated images.
-        loss_Dgen = 0
-        if do_Dmain:
-            with torch.autograd.profiler.record_function('Dgen_forward'):
-                gen_img, _ = self.run_G(gen_z, gen_c, sync=False)
-                gen_logits = self.run_D(gen_img, gen_c, sync=False)
-                training_stats.report('Loss/scores/fake', gen_logits)
-                training_stats.report('Loss/signs/fake', gen_logits.sign())
-                loss_Dgen = torch.nn.functional.softplus(gen_logits)
-            with torch.autograd.profiler.record_function('Dgen_backward'):
-                loss_Dgen.mean().mul(gain).backward()
-
-        # Dmain: maximise logits of real images.  Dr1: gradient penalty on reals.
-        if do_Dmain or do_Dr1:
-            name = 'Dreal_Dr1' if do_Dmain and do_Dr1 else 'Dreal' if do_Dmain else 'Dr1'
-            with torch.autograd.profiler.record_function(name + '_forward'):
-                real_img_tmp = real_img.detach().requires_grad_(do_Dr1)
-                with fused_layer.differentiable_twice() if do_Dr1 else contextlib.nullcontext():
-                    real_logits = self.run_D(real_img_tmp, real_c, sync=sync)
-                training_stats.report('Loss/scores/real', real_logits)
-                training_stats.report('Loss/signs/real', real_logits.sign())
-                loss_Dreal = 0
-                if do_Dmain:
-                    loss_Dreal = torch.nn.functional.softplus(-real_logits)
-                    training_stats.report('Loss/D/loss', loss_Dgen + loss_Dreal)
-                loss_Dr1 = 0
-                if do_Dr1:
-                    with torch.autograd.profiler.record_function('r1_grads'), conv2d_gradfix.no_weight_gradients():
-                        r1_grads = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_img_tmp],
-                                                       create_graph=True, only_inputs=True)[0]
-                    r1_penalty = r1_grads.square().sum([1, 2, 3])
-                    loss_Dr1 = r1_penalty * (self.r1_gamma / 2)
-                    training_stats.report('Loss/r1_penalty', r1_penalty)
-                    training_stats.report('Loss/D/reg', loss_Dr1)
-            with torch.autograd.profiler.record_function(name + '_backward'):
-                self._arm(sync)                  # (the Dgen pass before it is not final)
-                (real_logits * 0 + loss_Dreal + loss_Dr1).mean().mul(gain).backward()
+        groups = self._merged_groups(gen_z.shape[0], real_img.shape[0]) if d_main and not d_reg else None
+        if groups is not None:
+            self._d_main_merged(groups, real_img, real_c, gen_z, gen_c, gain, final=sync)
+            return
+        loss_fake = self._d_fake(gen_z, gen_c, gain) if d_main else 0
+        self._d_real(real_img, real_c, gain, final=sync, with_main=d_main, with_r1=d_reg, loss_fake=loss_fake)

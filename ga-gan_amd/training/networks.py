@@ -626,116 +626,127 @@ class ToRGBLayer(torch.nn.Module):
         return bias_act.bias_act(x, bias, clamp=self.conv_clamp)
 
 
+def _channels_per_resolution(resolutions, channel_base, channel_max):
+    """Feature maps at each resolution: channel_base / resolution, capped (reference: training/networks.py:1098, :1394)."""
+    return {res: min(channel_base // res, channel_max) for res in resolutions}
+
+
+def _first_low_precision_resolution(img_resolution_log2, num_fp16_res):
+    """The `num_fp16_res` highest resolutions run in 16 bits, never below 8 x 8 (reference: :1099, :1395)."""
+    return max(2 ** (img_resolution_log2 + 1 - num_fp16_res), 8)
+
+
+def _block_precision(block, force_fp32):
+    """(dtype, memory format) of a block's activations."""
+    low = block.use_fp16 and not force_fp32
+    return (LOW_PRECISION_DTYPE if low else torch.float32,
+            torch.channels_last if block.channels_last and not force_fp32 else torch.contiguous_format)
+
+
 class SynthesisBlock(torch.nn.Module):
+    """One resolution of the generator: [const | conv0 (up 2)] -> conv1 -> to-RGB added to the up-sampled image.
+    Sub-module and parameter names are the reference's (training/networks.py:968-1026); the forward pass is the
+    upstream wiring (:1028-1074 with the image up-sampling inside `if img is not None`)."""
+
     def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
                  resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False,
                  **layer_kwargs):
-        assert architecture in ['orig', 'skip', 'resnet']
+        if architecture not in ('orig', 'skip', 'resnet'):
+            raise AssertionError(f'unknown architecture {architecture!r}')
         super().__init__()
-        self.in_channels = in_channels
-        self.w_dim = w_dim
-        self.resolution = resolution
-        self.img_channels = img_channels
-        self.is_last = is_last
-        self.architecture = architecture
+        self.in_channels, self.w_dim, self.resolution = in_channels, w_dim, resolution
+        self.img_channels, self.is_last, self.architecture = img_channels, is_last, architecture
         self.use_fp16 = use_fp16
-        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.channels_last = use_fp16 and fp16_channels_last
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.num_conv = 0
-        self.num_torgb = 0
-        if in_channels == 0:
+        first = in_channels == 0                      # the 4 x 4 block starts from a learned constant
+        shared = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+        if first:
             self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
-        if in_channels != 0:
-            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
-                                        resample_filter=resample_filter, conv_clamp=conv_clamp,
-                                        channels_last=self.channels_last, **layer_kwargs)
-            self.num_conv += 1
-        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution,
-                                    conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
-        self.num_conv += 1
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, up=2, resample_filter=resample_filter, **shared)
+        self.conv1 = SynthesisLayer(out_channels, out_channels, **shared)
+        self.num_conv = 1 if first else 2
+        self.num_torgb = 0
         if is_last or architecture == 'skip':
-            self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, resolution=resolution,
-                                    conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
-            self.num_torgb += 1
-        if in_channels != 0 and architecture == 'resnet':
+            self.torgb = ToRGBLayer(out_channels, img_channels, **shared)
+            self.num_torgb = 1
+        if not first and architecture == 'resnet':
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
+    def _features(self, x, ws, layer_kwargs):
+        """The block's feature maps from the previous block's (or the constant); consumes num_conv rows of ws."""
+        if self.in_channels == 0:
+            return self.conv1(x, ws[0], **layer_kwargs)
+        if self.architecture != 'resnet':
+            return self.conv1(self.conv0(x, ws[0], **layer_kwargs), ws[1], **layer_kwargs)
+        shortcut = self.skip(x, gain=np.sqrt(0.5))
+        x = self.conv0(x, ws[0], **layer_kwargs)
+        x = self.conv1(x, ws[1], gain=np.sqrt(0.5), **layer_kwargs)
+        return shortcut.add_(x)
+
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
-        w_iter = iter(ws.unbind(dim=1))
-        dtype = LOW_PRECISION_DTYPE if self.use_fp16 and not force_fp32 else torch.float32
-        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
-        if fused_modconv is None:
+        dtype, memory_format = _block_precision(self, force_fp32)
+        if fused_modconv is None:     # per-sample weights only for inference, where they need no weight gradient
             fused_modconv = (not self.training) and (dtype == torch.float32 or int(ws.shape[0]) == 1)
+        layer_kwargs = dict(layer_kwargs, fused_modconv=fused_modconv)
+        ws = ws.unbind(dim=1)
 
         if self.in_channels == 0:
-            x = self.const.to(dtype=dtype, memory_format=memory_format)
-            x = x.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self.const.to(dtype=dtype, memory_format=memory_format).unsqueeze(0).repeat([ws[0].shape[0], 1, 1, 1])
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
             x = x.to(dtype=dtype, memory_format=memory_format)
-
-        if self.in_channels == 0:
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-        elif self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
-            x = y.add_(x)
-        else:
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        x = self._features(x, ws, layer_kwargs)
 
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        if self.is_last or self.architecture == 'skip':
-            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
-            img = img.add_(y) if img is not None else y
+        if self.num_torgb:
+            rgb = self.torgb(x, ws[self.num_conv], **layer_kwargs).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            img = rgb if img is None else img.add_(rgb)
 
-        assert x.dtype == dtype
-        assert img is None or img.dtype == torch.float32
+        assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img
 
 
 class SynthesisNetwork(torch.nn.Module):
+    """Blocks b4 .. b<img_resolution>; row k of `ws` feeds the k-th convolution in order, and a block's to-RGB
+    layer shares the row of the next block's first convolution (reference: training/networks.py:1079-1132)."""
+
     def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0,
                  **block_kwargs):
-        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        if img_resolution < 4 or img_resolution & (img_resolution - 1):
+            raise AssertionError('img_resolution must be a power of two, at least 4')
         super().__init__()
-        self.w_dim = w_dim
-        self.img_resolution = img_resolution
+        self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.img_channels = img_channels
         self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
-        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
-        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        channels = _channels_per_resolution(self.block_resolutions, channel_base, channel_max)
+        low_from = _first_low_precision_resolution(self.img_resolution_log2, num_fp16_res)
         self.num_ws = 0
         for res in self.block_resolutions:
-            in_channels = channels_dict[res // 2] if res > 4 else 0
-            block = SynthesisBlock(in_channels, channels_dict[res], w_dim=w_dim, resolution=res,
-                                   img_channels=img_channels, is_last=(res == self.img_resolution),
-                                   use_fp16=(res >= fp16_resolution), **block_kwargs)
-            self.num_ws += block.num_conv
-            if res == self.img_resolution:
-                self.num_ws += block.num_torgb
+            last = res == img_resolution
+            block = SynthesisBlock(channels[res // 2] if res > 4 else 0, channels[res], w_dim=w_dim, resolution=res,
+                                   img_channels=img_channels, is_last=last, use_fp16=(res >= low_from), **block_kwargs)
+            self.num_ws += block.num_conv + (block.num_torgb if last else 0)
             setattr(self, f'b{res}', block)
 
     def forward(self, ws, **block_kwargs):
-        block_ws = []
         with torch.autograd.profiler.record_function('split_ws'):
             misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
             ws = ws.to(torch.float32)
-            w_idx = 0
+            blocks, rows, first = [], [], 0
             for res in self.block_resolutions:
                 block = getattr(self, f'b{res}')
-                block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
-                w_idx += block.num_conv
+                blocks.append(block)
+                rows.append(ws.narrow(1, first, block.num_conv + block.num_torgb))
+                first += block.num_conv       # (the to-RGB row is the next block's first row)
         x = img = None
-        for res, cur_ws in zip(self.block_resolutions, block_ws):
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+        for block, block_ws in zip(blocks, rows):
+            x, img = block(x, img, block_ws, **block_kwargs)
         return img
 
 
@@ -764,61 +775,53 @@ class Generator(torch.nn.Module):
 # ----------------------------------------------------------------------------
 
 class DiscriminatorBlock(torch.nn.Module):
+    """One resolution of the discriminator: [from-RGB] -> conv0 -> conv1 (down 2), with a 1x1 down-sampling shortcut in
+    the 'resnet' architecture.  Names and layer numbering (Freeze-D) follow training/networks.py:1176-1242."""
+
     def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx,
                  architecture='resnet', activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None,
                  use_fp16=False, fp16_channels_last=False, freeze_layers=0, **_):
-        assert in_channels in [0, tmp_channels]
-        assert architecture in ['orig', 'skip', 'resnet']
+        if in_channels not in (0, tmp_channels) or architecture not in ('orig', 'skip', 'resnet'):
+            raise AssertionError('bad DiscriminatorBlock configuration')
         super().__init__()
-        self.in_channels = in_channels
-        self.resolution = resolution
-        self.img_channels = img_channels
-        self.first_layer_idx = first_layer_idx
-        self.architecture = architecture
-        self.use_fp16 = use_fp16
-        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.in_channels, self.resolution, self.img_channels = in_channels, resolution, img_channels
+        self.first_layer_idx, self.architecture, self.use_fp16 = first_layer_idx, architecture, use_fp16
+        self.channels_last = use_fp16 and fp16_channels_last
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
         self.num_layers = 0
 
-        def next_trainable():   # Freeze-D: the first `freeze_layers` layers of D are buffers
-            trainable = (self.first_layer_idx + self.num_layers) >= freeze_layers
+        def layer(cin, cout, kernel_size, **kwargs):
+            """The block's next layer; the discriminator's first `freeze_layers` layers hold buffers, not parameters."""
+            trainable = first_layer_idx + self.num_layers >= freeze_layers
             self.num_layers += 1
-            return trainable
+            return Conv2dLayer(cin, cout, kernel_size=kernel_size, trainable=trainable, channels_last=self.channels_last, **kwargs)
 
-        if in_channels == 0 or architecture == 'skip':
-            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation,
-                                       trainable=next_trainable(), conv_clamp=conv_clamp,
-                                       channels_last=self.channels_last)
-        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation,
-                                 trainable=next_trainable(), conv_clamp=conv_clamp, channels_last=self.channels_last)
-        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2,
-                                 trainable=next_trainable(), resample_filter=resample_filter, conv_clamp=conv_clamp,
-                                 channels_last=self.channels_last)
+        self.reads_image = in_channels == 0 or architecture == 'skip'
+        if self.reads_image:
+            self.fromrgb = layer(img_channels, tmp_channels, 1, activation=activation, conv_clamp=conv_clamp)
+        self.conv0 = layer(tmp_channels, tmp_channels, 3, activation=activation, conv_clamp=conv_clamp)
+        self.conv1 = layer(tmp_channels, out_channels, 3, activation=activation, down=2, resample_filter=resample_filter,
+                           conv_clamp=conv_clamp)
         if architecture == 'resnet':
-            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2,
-                                    trainable=next_trainable(), resample_filter=resample_filter,
-                                    channels_last=self.channels_last)
+            self.skip = layer(tmp_channels, out_channels, 1, bias=False, down=2, resample_filter=resample_filter)
 
     def forward(self, x, img, force_fp32=False):
-        dtype = LOW_PRECISION_DTYPE if self.use_fp16 and not force_fp32 else torch.float32
-        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        dtype, memory_format = _block_precision(self, force_fp32)
         if x is not None:
             misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
             x = x.to(dtype=dtype, memory_format=memory_format)
-        if self.in_channels == 0 or self.architecture == 'skip':
+        if self.reads_image:
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
             img = img.to(dtype=dtype, memory_format=memory_format)
-            y = self.fromrgb(img)
-            x = x + y if x is not None else y
+            features = self.fromrgb(img)
+            x = features if x is None else x + features
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
-            x, y = self.skip(x, gain=np.sqrt(0.5), also_input=True)
-            x = self.conv0(x)
-            x = self.conv1(x, gain=np.sqrt(0.5))
-            x = y.add_(x)
+            half = np.sqrt(0.5)                       # both branches scaled so that their sum keeps the variance
+            x, shortcut = self.skip(x, gain=half, also_input=True)
+            x = shortcut.add_(self.conv1(self.conv0(x), gain=half))
         else:
-            x = self.conv0(x)
-            x = self.conv1(x)
+            x = self.conv1(self.conv0(x))
         assert x.dtype == dtype
         return x, img
 
@@ -871,35 +874,30 @@ class DiscriminatorEpilogue(torch.nn.Module):
 
 
 class Discriminator(torch.nn.Module):
+    """Blocks b<img_resolution> .. b8, then the 4 x 4 epilogue b4 (reference: training/networks.py:1372-1437)."""
+
     def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768,
                  channel_max=512, num_fp16_res=0, conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={},
                  epilogue_kwargs={}):
         super().__init__()
-        self.c_dim = c_dim
-        self.img_resolution = img_resolution
+        self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.img_channels = img_channels
         self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
-        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
-        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
-        if cmap_dim is None:
-            cmap_dim = channels_dict[4]
-        if c_dim == 0:
-            cmap_dim = 0
-        common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
-        cur_layer_idx = 0
+        channels = _channels_per_resolution(self.block_resolutions + [4], channel_base, channel_max)
+        low_from = _first_low_precision_resolution(self.img_resolution_log2, num_fp16_res)
+        cmap_dim = 0 if c_dim == 0 else (channels[4] if cmap_dim is None else cmap_dim)
+        shared = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        layers_so_far = 0
         for res in self.block_resolutions:
-            in_channels = channels_dict[res] if res < img_resolution else 0
-            block = DiscriminatorBlock(in_channels, channels_dict[res], channels_dict[res // 2], resolution=res,
-                                       first_layer_idx=cur_layer_idx, use_fp16=(res >= fp16_resolution),
-                                       **block_kwargs, **common_kwargs)
+            block = DiscriminatorBlock(channels[res] if res < img_resolution else 0, channels[res], channels[res // 2],
+                                       resolution=res, first_layer_idx=layers_so_far, use_fp16=(res >= low_from),
+                                       **block_kwargs, **shared)
             setattr(self, f'b{res}', block)
-            cur_layer_idx += block.num_layers
+            layers_so_far += block.num_layers
         if c_dim > 0:
             self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None,
                                           **mapping_kwargs)
-        self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs,
-                                        **common_kwargs)
+        self.b4 = DiscriminatorEpilogue(channels[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **shared)
 
     def largest_activation_elements(self):
         """Upper bound of the elements per sample of the largest tensor a pass makes (the first block's: its channels

@@ -53,13 +53,12 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
         f_w=f.shape[1], f_h=f.shape[0], f_stride_w=f.stride(1), f_stride_h=f.stride(0),
         out_w=out_w, out_h=out_h,
         out_stride_w=y.stride(3), out_stride_h=y.stride(2), out_stride_c=y.stride(1), out_stride_n=y.stride(0))
-    tiled = (x.stride(3) == 1 and y.stride(3) == 1 and x.dtype != torch.float64 and f.shape[0] <= 4 and f.shape[1] <= 4
-             and (upx, upy, downx, downy) in ((1, 1, 1, 1), (2, 2, 1, 1), (1, 1, 2, 2)))
-    if tiled and upx == upy == downx == downy == 1:
-        label = 'upfirdn2d_blur4_kernel'
-    else:
-        label = f'upfirdn2d_tiled_kernel<up{upx} down{downx}>' if tiled else 'upfirdn2d_generic_kernel'
-    if _DETAIL:
+    label = ''
+    if _lib.profiling():     # the symbol a profiler shows for this launch
+        label = _lib.lib().sg_upfirdn2d_kernel(ctypes.byref(p), None).decode()
+        if label == 'upfirdn2d_tiled_kernel':
+            label += f'<up{upx} down{downx}>'
+    if _DETAIL and label:
         label += f' {c}x{h}x{w} n{n} {str(x.dtype)[6:]}'
     _lib.launch('sg_upfirdn2d', p, x, label, _lib.nbytes(x, y))
     return y
@@ -88,7 +87,7 @@ def upfirdn2d_add(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip
         out_stride_w=y.stride(3), out_stride_h=y.stride(2), out_stride_c=y.stride(1), out_stride_n=y.stride(0))
     if not _lib.lib().sg_upfirdn2d_add_supported(ctypes.byref(p)):
         return None
-    label = f'upfirdn2d_add<up{upx} down{downx}>'
+    label = 'up2_stream_kernel'
     if _DETAIL:
         label += f' {c}x{h}x{w} n{n} {str(x.dtype)[6:]}'
     fn = _lib.lib().sg_upfirdn2d_add

@@ -125,6 +125,13 @@ typedef struct sg_epilogue {
  * contiguous; other geometries return SG_ERR_UNSUPPORTED).  `ep` may be NULL (= sg_upfirdn2d). */
 int sg_upfirdn2d_epilogue(const sg_upfirdn2d_params* p, const sg_epilogue* ep, sg_stream_t stream);
 
+/* Name of the device kernel sg_upfirdn2d (ep == NULL) or sg_upfirdn2d_epilogue (ep != NULL) runs for this geometry:
+ * the symbol a profiler reports, without template arguments ("blur4_stream_kernel", "down2_stream_kernel",
+ * "up2_stream_kernel": the streaming kernels for 16-bit planes of whole aligned packets; "upfirdn2d_blur4_kernel",
+ * "upfirdn2d_tiled_kernel", "upfirdn2d_generic_kernel" otherwise).  Static storage.  No counterpart in the
+ * reference, whose choice among its kernel specialisations (upfirdn2d.cu:205-341) is not observable. */
+const char* sg_upfirdn2d_kernel(const sg_upfirdn2d_params* p, const sg_epilogue* ep);
+
 /* Backward of the epilogue, one pass over dy and y (dense [n, c, hw] of `dtype`):
  *   g  = dy * gain * act'(.)  (zero where y was clamped; the activation's slope is taken from sign(y))
  *   dz = g * scale[n,c]                                   -> gradient w.r.t. the pre-epilogue value v

@@ -41,7 +41,11 @@ def run_launcher(monkeypatch, argv, devices, rcs):
         return proc
 
     import torch
-    monkeypatch.setattr(torch.cuda, 'device_count', lambda: devices)
+
+    def forbidden():
+        raise AssertionError('the launcher parent must not ask the HIP runtime for the device count')
+    monkeypatch.setattr(torch.cuda, 'device_count', forbidden)
+    monkeypatch.setattr(bench, 'visible_gpus', lambda: devices)
     monkeypatch.setattr(bench.subprocess, 'Popen', popen)
     monkeypatch.setattr(sys, 'argv', ['bench.py'] + argv)
     monkeypatch.delenv('WORLD_SIZE', raising=False)
@@ -79,3 +83,16 @@ def test_rank_refuses_mismatched_world(monkeypatch):
     monkeypatch.setenv('WORLD_SIZE', '4')
     with pytest.raises(SystemExit, match='WORLD_SIZE is 4'):
         bench.main()
+
+
+def test_visible_gpus_reads_the_environment_first(monkeypatch):
+    bench = load_bench()
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,2,5')
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    count = bench.visible_gpus()        # the driver's topology, or None where there is none to read
+    assert count is None or count >= 0
