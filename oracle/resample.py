@@ -124,9 +124,12 @@ def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True
     return F.conv2d(x, w, stride=stride, padding=padding, groups=groups)
 
 
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, between=None):
     """Convolution with optional FIR up/down-sampling; the six execution paths
-    of torch_utils/ops/conv2d_resample.py:106-154 in the same order."""
+    of torch_utils/ops/conv2d_resample.py:106-154 in the same order.
+    `between`: applied to the tensor that passes from the first of a path's two operations to the second (the
+    place where an implementation that keeps its tensors in 16 bits rounds)."""
+    between = between or (lambda t: t)
     cout, cin_g, kh, kw = w.shape
     fw, fh = filter_extent(f)
     px0, px1, py0, py1 = quad_padding(padding)
@@ -142,13 +145,13 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         py1 += (fh - down) // 2
 
     if kw == 1 and kh == 1 and down > 1 and up == 1:          # decimate, then 1x1
-        x = upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
+        x = between(upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter))
         return _conv(x, w, groups=groups, flip_weight=flip_weight)
     if kw == 1 and kh == 1 and up > 1 and down == 1:          # 1x1, then interpolate
-        x = _conv(x, w, groups=groups, flip_weight=flip_weight)
+        x = between(_conv(x, w, groups=groups, flip_weight=flip_weight))
         return upfirdn2d(x, f, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
     if down > 1 and up == 1:                                  # blur, then strided conv
-        x = upfirdn2d(x, f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
+        x = between(upfirdn2d(x, f, padding=[px0, px1, py0, py1], flip_filter=flip_filter))
         return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight)
     if up > 1:                                                # transposed conv, then blur
         if groups == 1:
@@ -162,7 +165,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         py1 -= kh - up
         pxt = max(min(-px0, -px1), 0)
         pyt = max(min(-py0, -py1), 0)
-        x = _conv(x, wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=not flip_weight)
+        x = between(_conv(x, wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=not flip_weight))
         x = upfirdn2d(x, f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
         if down > 1:
             x = upfirdn2d(x, f, down=down, flip_filter=flip_filter)

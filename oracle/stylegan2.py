@@ -16,7 +16,18 @@ unchanged.  Restates:
 All arithmetic runs in the dtype of the inputs (float32 or float64); the
 half-precision pre-normalisation of training/networks.py:621-627 is a no-op
 for these dtypes and is not restated.
+
+Inside `low_precision(dtype, from_resolution)` the blocks at and above that
+resolution (the reference's `use_fp16` blocks, networks.py:1031, :1245) still
+compute in the inputs' dtype, but every tensor that an implementation with
+16-bit storage keeps in memory there is rounded to `dtype` and back: layer
+inputs after modulation, weights and biases, layer outputs, the tensor between
+a resampling filter and its convolution, and - in the backward pass - the
+gradients with respect to layer inputs and convolution outputs.  Sums inside
+a convolution or filter stay unrounded (16-bit kernels accumulate in float32).
+This is the yardstick for 16-bit runs: how far rounding alone moves a result.
 """
+import contextlib
 import math
 import re
 from dataclasses import dataclass, field
@@ -113,6 +124,96 @@ class DiscriminatorConfig:
 _FILTER = resample.make_filter([1, 3, 3, 1])
 
 
+# ----------------------------------------------------------------------------
+# 16-bit storage emulation (see the module text).
+
+_LOW = None      # (dtype, first resolution, channels above which an up-sampling layer runs as two 16-bit passes)
+
+
+@contextlib.contextmanager
+def low_precision(dtype=torch.bfloat16, from_resolution=8, two_pass_up_above=128):
+    global _LOW
+    old, _LOW = _LOW, (dtype, from_resolution, two_pass_up_above)
+    try:
+        yield
+    finally:
+        _LOW = old
+
+
+def _low_dtype(res):
+    return _LOW[0] if _LOW is not None and res >= _LOW[1] else None
+
+
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype, values, gradients):
+        ctx.dtype, ctx.gradients = dtype, gradients
+        return x.to(dtype).to(x.dtype) if values else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dtype).to(g.dtype) if ctx.gradients else g), None, None, None
+
+
+class _LowEpilogue(torch.autograd.Function):
+    """y = clamp(lrelu(v * scale[n, c] + noise + bias[c]) * gain) stored in 16 bits, with the backward pass of an
+    implementation that keeps nothing but that stored output: slope and clamp mask from the sign and size of y, the
+    pre-activation recovered from y for the gradient of `scale`, and the gradient with respect to v rounded to 16
+    bits.  (First order only.)"""
+
+    @staticmethod
+    def forward(ctx, v, scale, noise, bias, alpha, gain, clamp, low):
+        u = v * scale.to(v.dtype).reshape(v.shape[0], -1, 1, 1) + bias.to(v.dtype).reshape(1, -1, 1, 1)
+        if noise is not None:
+            u = u + noise.to(v.dtype)
+        y = torch.where(u > 0, u, u * alpha) * gain
+        if clamp is not None:
+            y = y.clamp(-clamp, clamp)
+        y = y.to(low).to(v.dtype)
+        ctx.save_for_backward(y, scale, noise, bias)
+        ctx.cfg = (alpha, gain, clamp, low)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale, noise, bias = ctx.saved_tensors
+        alpha, gain, clamp, low = ctx.cfg
+        n = y.shape[0]
+        g = dy * gain
+        g = torch.where(y > 0, g, g * alpha)
+        if clamp is not None:
+            g = torch.where((y > -clamp) & (y < clamp), g, torch.zeros_like(g))
+        sc = scale.to(y.dtype).reshape(n, -1, 1, 1)
+        dv = (g * sc).to(low).to(y.dtype)
+        t = y / gain
+        t = torch.where(t < 0, t / alpha, t)                       # the pre-activation, from the stored output
+        rest = t - bias.to(y.dtype).reshape(1, -1, 1, 1)
+        if noise is not None:
+            rest = rest - noise.to(y.dtype)
+        dscale = ((g * rest).sum(dim=[2, 3]) / scale.to(y.dtype)).to(scale.dtype)
+        dnoise = None
+        if noise is not None and noise.requires_grad:
+            dnoise = g.sum(dim=1, keepdim=True)
+            while dnoise.ndim > noise.ndim:
+                dnoise = dnoise.sum(dim=0)
+            for d in range(noise.ndim):
+                if noise.shape[d] == 1 and dnoise.shape[d] != 1:
+                    dnoise = dnoise.sum(dim=d, keepdim=True)
+            dnoise = dnoise.to(noise.dtype)
+        dbias = g.sum(dim=[0, 2, 3]).to(bias.dtype)
+        return dv, dscale, dnoise, dbias, None, None, None, None
+
+
+def _rv(x, low):
+    """Round the values of x to the 16-bit dtype `low` (None: leave)."""
+    return x if low is None or x is None else _Round.apply(x, low, True, False)
+
+
+def _rg(x, low):
+    """Round the gradient that flows back through this point."""
+    return x if low is None or x is None or not x.requires_grad else _Round.apply(x, low, False, True)
+
+
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
@@ -190,7 +291,7 @@ def styles_from_w(p, prefix, w, weight_gain, kinds):
 # Layers.
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None,
-                     demodulate=True, flip_weight=True, fused_modconv=True):
+                     demodulate=True, flip_weight=True, fused_modconv=True, low=None, epilogue=None):
     n = x.shape[0]
     cout, cin, kh, kw = weight.shape
     w = dcoefs = None
@@ -200,9 +301,21 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
         dcoefs = (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
     if not fused_modconv:
         # scale activations, convolve with the shared weight, rescale outputs
-        x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
-        x = resample.conv2d_resample(x, weight.to(x.dtype), f=resample_filter, up=up, padding=padding,
-                                     flip_weight=flip_weight)
+        x = _rg(x, low)
+        if low is not None and kh == 1:       # (16-bit 1x1 layers fold the styles into their few weights in float32)
+            x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+        else:
+            x = _rv(x * styles.to(x.dtype).reshape(n, -1, 1, 1), low)
+        # an up-sampling layer keeps its transposed-convolution output in 16 bits when it runs as two passes (wide
+        # layers); its backward pass always has the gradient of that tensor in 16 bits
+        two_pass = low is not None and up > 1 and cin > _LOW[2]
+        x = resample.conv2d_resample(x, _rv(weight.to(x.dtype), low), f=resample_filter, up=up, padding=padding,
+                                     flip_weight=flip_weight, between=lambda t: _rg(_rv(t, low) if two_pass else t, low))
+        if low is not None and demodulate and epilogue is not None:
+            # the layer's epilogue as ONE operation on the convolution output (see _LowEpilogue)
+            bias, alpha, gain, clamp = epilogue
+            return _LowEpilogue.apply(x, dcoefs, noise, bias, alpha, gain, clamp, low)
+        x = _rg(x, low)
         if demodulate:
             x = x * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
         if noise is not None:
@@ -220,19 +333,20 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     return x
 
 
-def conv2d_layer(p, prefix, x, activation='linear', up=1, down=1, conv_clamp=None, gain=1.0):
+def conv2d_layer(p, prefix, x, activation='linear', up=1, down=1, conv_clamp=None, gain=1.0, low=None):
     w = p[prefix + 'weight']
     cout, cin, k, _ = w.shape
-    w = (w * (1 / math.sqrt(cin * k * k))).to(x.dtype)
+    w = _rv((w * (1 / math.sqrt(cin * k * k))).to(x.dtype), low)
     b = p.get(prefix + 'bias')
-    b = b.to(x.dtype) if b is not None else None
-    x = resample.conv2d_resample(x, w, f=_FILTER, up=up, down=down, padding=k // 2, flip_weight=(up == 1))
+    b = _rv(b.to(x.dtype), low) if b is not None else None
+    x = resample.conv2d_resample(_rg(x, low), w, f=_FILTER, up=up, down=down, padding=k // 2, flip_weight=(up == 1),
+                                 between=lambda t: _rg(_rv(t, low), low))
     act_gain = pointwise.ACTIVATIONS[activation][2] * gain
     act_clamp = conv_clamp * gain if conv_clamp is not None else None
-    return pointwise.bias_act(x, b, act=activation, gain=act_gain, clamp=act_clamp)
+    return _rv(pointwise.bias_act(_rg(x, low), b, act=activation, gain=act_gain, clamp=act_clamp), low)
 
 
-def synthesis_layer(p, prefix, x, w, cfg, kinds, up=1, noise_mode='const', noise=None, fused_modconv=False, gain=1.0):
+def synthesis_layer(p, prefix, x, w, cfg, kinds, up=1, noise_mode='const', noise=None, fused_modconv=False, gain=1.0, low=None):
     styles = styles_from_w(p, prefix, w, 1.0, kinds)
     weight = effective_conv_weight(p, prefix, kinds[1])
     res = x.shape[2] * up
@@ -242,18 +356,22 @@ def synthesis_layer(p, prefix, x, w, cfg, kinds, up=1, noise_mode='const', noise
         nz = rnd * p[prefix + 'noise_strength']
     elif cfg.use_noise and noise_mode == 'const':
         nz = p[prefix + 'noise_const'] * p[prefix + 'noise_strength']
-    x = modulated_conv2d(x, weight, styles, noise=nz, up=up, padding=weight.shape[2] // 2, resample_filter=_FILTER,
-                         flip_weight=(up == 1), fused_modconv=fused_modconv)
     act_gain = pointwise.ACTIVATIONS['lrelu'][2] * gain
     act_clamp = cfg.conv_clamp * gain if cfg.conv_clamp is not None else None
-    return pointwise.bias_act(x, p[prefix + 'bias'].to(x.dtype), act='lrelu', gain=act_gain, clamp=act_clamp)
+    if low is not None and not fused_modconv:
+        return modulated_conv2d(x, weight, styles, noise=nz, up=up, padding=weight.shape[2] // 2, resample_filter=_FILTER,
+                                flip_weight=(up == 1), fused_modconv=False, low=low,
+                                epilogue=(_rv(p[prefix + 'bias'].to(x.dtype), low), pointwise.ACTIVATIONS['lrelu'][1], act_gain, act_clamp))
+    x = modulated_conv2d(x, weight, styles, noise=nz, up=up, padding=weight.shape[2] // 2, resample_filter=_FILTER,
+                         flip_weight=(up == 1), fused_modconv=fused_modconv, low=low)
+    return _rv(pointwise.bias_act(x, _rv(p[prefix + 'bias'].to(x.dtype), low), act='lrelu', gain=act_gain, clamp=act_clamp), low)
 
 
-def torgb_layer(p, prefix, x, w, cfg, kinds, fused_modconv=False):
+def torgb_layer(p, prefix, x, w, cfg, kinds, fused_modconv=False, low=None):
     weight = effective_conv_weight(p, prefix, kinds[1])
     styles = styles_from_w(p, prefix, w, 1 / math.sqrt(weight.shape[1] * weight.shape[2] ** 2), kinds)
-    x = modulated_conv2d(x, weight, styles, demodulate=False, fused_modconv=fused_modconv)
-    return pointwise.bias_act(x, p[prefix + 'bias'].to(x.dtype), clamp=cfg.conv_clamp)
+    x = modulated_conv2d(x, weight, styles, demodulate=False, fused_modconv=fused_modconv, low=low)
+    return _rg(_rv(pointwise.bias_act(x, _rv(p[prefix + 'bias'].to(x.dtype), low), clamp=cfg.conv_clamp), low), low)
 
 
 # ----------------------------------------------------------------------------
@@ -290,7 +408,7 @@ def w_avg_update(w_avg, w_batch, beta):
     return w_batch.detach().mean(dim=0).lerp(w_avg, beta)
 
 
-def synthesis(p, ws, cfg, prefix='synthesis.', noise_mode='const', fused_modconv=False, noises=None):
+def synthesis(p, ws, cfg, prefix='synthesis.', noise_mode='const', fused_modconv=False, noises=None, taps=None):
     kinds = split_parametrization(cfg.use_domain_modulation, cfg.domain_modulation_parametrization)
     ws = ws.to(torch.float64 if ws.dtype == torch.float64 else torch.float32)
     x = img = None
@@ -303,22 +421,30 @@ def synthesis(p, ws, cfg, prefix='synthesis.', noise_mode='const', fused_modconv
         w_idx += num_conv
         it = iter(bw.unbind(dim=1))
         nz = (noises or {}).get
-        lk = dict(cfg=cfg, kinds=kinds, noise_mode=noise_mode, fused_modconv=fused_modconv)
+        low = _low_dtype(res)
+        lk = dict(cfg=cfg, kinds=kinds, noise_mode=noise_mode, fused_modconv=fused_modconv, low=low)
+        if x is not None:
+            x = _rv(x, low)     # (entering the first 16-bit block)
         if res == 4:
             x = p[bp + 'const'].to(ws.dtype).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
             x = synthesis_layer(p, bp + 'conv1.', x, next(it), noise=nz(bp + 'conv1'), **lk)
         elif cfg.architecture == 'resnet':
-            y = conv2d_layer(p, bp + 'skip.', x, up=2, gain=math.sqrt(0.5))
+            y = conv2d_layer(p, bp + 'skip.', x, up=2, gain=math.sqrt(0.5), low=low)
             x = synthesis_layer(p, bp + 'conv0.', x, next(it), up=2, noise=nz(bp + 'conv0'), **lk)
             x = synthesis_layer(p, bp + 'conv1.', x, next(it), noise=nz(bp + 'conv1'), gain=math.sqrt(0.5), **lk)
-            x = y + x
+            x = _rv(y + x, low)
         else:
             x = synthesis_layer(p, bp + 'conv0.', x, next(it), up=2, noise=nz(bp + 'conv0'), **lk)
+            if taps is not None:
+                taps[f'b{res}.conv0'] = x
             x = synthesis_layer(p, bp + 'conv1.', x, next(it), noise=nz(bp + 'conv1'), **lk)
+        x = _rg(x, low)          # (two consumers: the sum of their gradients is a 16-bit tensor)
+        if taps is not None:
+            taps[f'b{res}'] = x
         if img is not None:
             img = resample.upsample2d(img, _FILTER)
         if has_rgb:
-            y = torgb_layer(p, bp + 'torgb.', x, next(it), cfg, kinds, fused_modconv=fused_modconv)
+            y = torgb_layer(p, bp + 'torgb.', x, next(it), cfg, kinds, fused_modconv=fused_modconv, low=low)
             img = img + y if img is not None else y
     return img
 
@@ -337,18 +463,20 @@ def discriminator(p, img, c, cfg):
     cc = cfg.conv_clamp
     for res in cfg.block_resolutions:
         bp = f'b{res}.'
+        low = _low_dtype(res)
         if x is None or arch == 'skip':
-            y = conv2d_layer(p, bp + 'fromrgb.', img, activation='lrelu', conv_clamp=cc)
-            x = x + y if x is not None else y
+            y = conv2d_layer(p, bp + 'fromrgb.', _rv(img, low), activation='lrelu', conv_clamp=cc, low=low)
+            x = _rv(x + y, low) if x is not None else y
             img = resample.downsample2d(img, _FILTER) if arch == 'skip' else None
         if arch == 'resnet':
-            y = conv2d_layer(p, bp + 'skip.', x, down=2, gain=math.sqrt(0.5))
-            x = conv2d_layer(p, bp + 'conv0.', x, activation='lrelu', conv_clamp=cc)
-            x = conv2d_layer(p, bp + 'conv1.', x, activation='lrelu', down=2, conv_clamp=cc, gain=math.sqrt(0.5))
-            x = y + x
+            x = _rg(x, low)      # (two consumers: the sum of their gradients is a 16-bit tensor)
+            y = conv2d_layer(p, bp + 'skip.', x, down=2, gain=math.sqrt(0.5), low=low)
+            x = conv2d_layer(p, bp + 'conv0.', x, activation='lrelu', conv_clamp=cc, low=low)
+            x = conv2d_layer(p, bp + 'conv1.', x, activation='lrelu', down=2, conv_clamp=cc, gain=math.sqrt(0.5), low=low)
+            x = _rv(y + x, low)
         else:
-            x = conv2d_layer(p, bp + 'conv0.', x, activation='lrelu', conv_clamp=cc)
-            x = conv2d_layer(p, bp + 'conv1.', x, activation='lrelu', down=2, conv_clamp=cc)
+            x = conv2d_layer(p, bp + 'conv0.', x, activation='lrelu', conv_clamp=cc, low=low)
+            x = conv2d_layer(p, bp + 'conv1.', x, activation='lrelu', down=2, conv_clamp=cc, low=low)
 
     cmap_dim = cfg.cmap_dim if cfg.cmap_dim is not None else cfg.channels(4)
     if cfg.c_dim == 0:

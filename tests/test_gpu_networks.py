@@ -595,3 +595,113 @@ def test_trainer_snapshot_round_trip(tmp_path):
     b.step(*batches[2], gen_z=zs[2])             # (the restored trainer keeps training)
     assert (b.cur_nimg, b.batch_idx) == (12, 3)
     assert all(bool(torch.isfinite(p).all()) for p in list(b.G.parameters()) + list(b.D.parameters()))
+
+
+# ----------------------------------------------------------------------------
+# 16-bit runs against the oracle with 16-bit storage emulated (oracle.stylegan2.low_precision): the same layers in
+# float32 arithmetic, with every tensor that the product keeps in bfloat16 rounded at the same places.  Layer by
+# layer the two agree to 1e-5 .. 4e-4 (float32 sums in a different order move a result across a rounding boundary
+# for up to 1 % of the elements); through eight 16-bit layers those differences grow to the size of the rounding
+# noise itself, so the emulation cannot track a network element by element.  It gives two things instead:
+#   * a second evaluation with the same rounding noise: images, logits and well-conditioned gradients (the
+#     discriminator's) agree with it an order of magnitude closer than the float32 fixtures allow;
+#   * the size of that noise: for the generator's style gradients (cancelling sums, see above) the emulation's own
+#     distance from exact arithmetic bounds what any bfloat16 implementation can reach, and the product is held to
+#     1.5 times that distance per tensor.
+
+def _oracle():
+    from oracle import stylegan2 as sg
+    return sg
+
+
+def _report(tag, rows):
+    print(f'[{tag}] ' + '  '.join(f'{k} {v:.2e}' for k, v in rows))
+
+
+@pytest.mark.parametrize('case', [c for c in FULL if c.meta['kind'] == 'G'], ids=lambda c: c.meta['tag'])
+def test_full_size_generator_bf16_against_rounded_oracle(case):
+    from ga_gan_amd.training import training_loop
+    sg, m = _oracle(), case.meta
+    p = {name: seeded_fill(name, shape) for name, shape in zip(m['names'], m['shapes'])}
+    z = torch.randn(1, 512, generator=torch.Generator().manual_seed(m['z_seed']))
+    dy = torch.randn(1, 3, m['res'], m['res'], generator=torch.Generator().manual_seed(m['dy_seed']))
+    # the oracle, float32 arithmetic, bfloat16 storage in the four highest resolutions
+    leaves = {k: (v.clone().requires_grad_(True) if k in m['trainable'] else v) for k, v in p.items()}
+    cfg = sg.GeneratorConfig(img_resolution=m['res'], channel_base=m['channel_base'], conv_clamp=256, use_domain_modulation=True,
+                             domain_modulation_parametrization=m['parametrization'])
+    with sg.low_precision(torch.bfloat16, from_resolution=m['res'] // 8):
+        want_img = sg.generator(leaves, z, torch.zeros(1, 0), cfg, noise_mode='const', fused_modconv=False)
+        want = torch.autograd.grad((want_img * dy).sum(), [leaves[k] for k in m['trainable']])
+    # the product
+    G = networks().Generator(
+        z_dim=512, c_dim=0, w_dim=512, img_resolution=m['res'], img_channels=3, mapping_kwargs=dict(num_layers=8),
+        synthesis_kwargs=dict(channel_base=m['channel_base'], channel_max=512, num_fp16_res=4, conv_clamp=256,
+                              use_domain_modulation=True, domain_modulation_parametrization=m['parametrization'],
+                              generator_requires_grad_parts=m['parts']))
+    fill_seeded(G, m)
+    G.to(DEV).train()
+    training_loop.set_requires_grad(G, list(m['parts']))
+    img = G(z.to(DEV), torch.zeros(1, 0, device=DEV), noise_mode='const')
+    params = dict(G.named_parameters())
+    got = torch.autograd.grad((img * dy.to(DEV)).sum(), [params[k] for k in m['trainable']])
+
+    img_err = golden_io.rel_err(img.detach(), want_img.detach())
+    num = sum(float((g.detach().double().cpu() - w.double()).square().sum()) for g, w in zip(got, want))
+    den = sum(float(w.double().square().sum()) for w in want)
+    together = (num / den) ** 0.5
+    rows, bad, sq = [], {}, [0.0, 0.0, 0.0]
+    for k, g, w in zip(m['trainable'], got, want):
+        whole = 'g.' + k in case
+        exact = case.t(('xg.' if whole else 'xgs.') + k)        # the same gradient in float64 arithmetic
+        pick = (lambda t: t.detach().double().cpu()) if whole else (lambda t: t.detach().double().cpu().flatten()[::61])
+        floor, ours = golden_io.rel_err(pick(w), exact), golden_io.rel_err(pick(g), exact)
+        sq[0] += float((pick(g) - exact.double()).square().sum())
+        sq[1] += float((pick(w) - exact.double()).square().sum())
+        sq[2] += float(exact.double().square().sum())
+        rows.append((ours / max(floor, 1e-12), ours, floor, k))
+        if ours > max(2e-2, 3 * floor):          # (one tensor: a single draw of the noise on either side)
+            bad[k] = (ours, floor)
+    rows.sort(reverse=True)
+    ours_all, floor_all = (sq[0] / sq[2]) ** 0.5, (sq[1] / sq[2]) ** 0.5
+    _report(m['tag'], [('image vs emulation', img_err), ('all gradients vs emulation', together),
+                       ('all gradients vs exact', ours_all), ('the emulation\'s', floor_all),
+                       ('worst tensor, ratio to the emulation\'s own error', rows[0][0]), ('its error', rows[0][1])])
+    assert img_err < 1e-2
+    assert together < 8e-2
+    assert ours_all < max(2e-2, 1.5 * floor_all)      # all trainable gradients as one vector: the noise averages out
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('case', [c for c in FULL if c.meta['kind'] == 'D'], ids=lambda c: c.meta['tag'])
+def test_full_size_discriminator_bf16_against_rounded_oracle(case):
+    """Logits within 1e-2 of their magnitude, every parameter gradient within 2.5e-2 (relative L2) and the image
+    gradient within 4e-2 of the emulation (the float32 fixtures above allow 0.1 / 0.25)."""
+    sg, m = _oracle(), case.meta
+    p = {name: seeded_fill(name, shape) for name, shape in zip(m['names'], m['shapes'])}
+    n, res = m['batch'], m['res']
+    x = torch.randn(n, 3, res, res, generator=torch.Generator().manual_seed(m['img_seed'])).clamp_(-1, 1)
+    names = [k for k in m['names'] if k.endswith('.weight') or k.endswith('.bias')]
+    leaves = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
+    xo = x.clone().requires_grad_(True)
+    cfg = sg.DiscriminatorConfig(img_resolution=res, channel_base=m['channel_base'], conv_clamp=256, mbstd_group_size=m['mbstd_group_size'])
+    with sg.low_precision(torch.bfloat16, from_resolution=res // 8):
+        want_logits = sg.discriminator(leaves, xo, torch.zeros(n, 0), cfg)
+        want = torch.autograd.grad(want_logits.sum(), [xo] + [leaves[k] for k in names])
+    D = networks().Discriminator(c_dim=0, img_resolution=res, img_channels=3, channel_base=m['channel_base'], channel_max=512,
+                                 num_fp16_res=4, conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=m['mbstd_group_size']))
+    fill_seeded(D, m)
+    D.to(DEV).train().requires_grad_(True)
+    xg = x.to(DEV).requires_grad_(True)
+    logits = D(xg, torch.zeros(n, 0, device=DEV))
+    params = dict(D.named_parameters())
+    got = torch.autograd.grad(logits.sum(), [xg] + [params[k] for k in names])
+    scale = float(want_logits.detach().abs().max())
+    logit_err = float((logits.detach().cpu() - want_logits.detach()).abs().max()) / scale
+    errs = sorted(((golden_io.rel_err(g, w), k) for k, g, w in zip(['image'] + names, got, want)), reverse=True)
+    worst_param = next(e for e in errs if e[1] != 'image')
+    image_err = next(e for e in errs if e[1] == 'image')[0]
+    _report(m['tag'], [('logits', logit_err), ('image gradient', image_err), ('worst parameter gradient', worst_param[0]),
+                       ('median', errs[len(errs) // 2][0])])
+    assert logit_err < 1e-2
+    assert image_err < 4e-2
+    assert worst_param[0] < 2.5e-2, errs[:4]
