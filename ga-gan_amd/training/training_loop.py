@@ -135,20 +135,26 @@ def setup_training_options(cfg='paper256', resolution=256, batch_size=None, num_
 # Gradient exchange.
 
 class GradReducer:
-    """Average the gradients of a parameter list across ranks with as few collectives
-    as possible: gradients are packed into one flat buffer per dtype, all-reduced in
-    buckets of `bucket_bytes` (asynchronously, on RCCL's own stream), and unpacked in place.
+    """Average the gradients of a phase's parameters across ranks with as few collectives as possible and no copies:
+    the gradients LIVE in flat buffers (one per bucket of `bucket_bytes`), so a bucket is all-reduced where it lies.
 
-    Two ways to drive it:
-      * `reducer(params)` after the backward pass: pack, reduce, unpack;
-      * overlapped with the backward pass (what the trainer does): `attach(params)` once, `arm()`
-        right before the backward call whose gradients are final (the reference synchronises on exactly
-        that call: `sync` in training/loss.py:69-152, misc.ddp_sync), `finish(params)` after it.  While
-        armed, every parameter reports from autograd's post-accumulate hook the moment its gradient is
-        complete; a full bucket is packed and its all-reduce enqueued at once, so the exchange of the
-        layers that finish first runs under the backward pass of the remaining ones.  The discriminator
-        profits most: its 512-channel low-resolution weights - most of its bytes - are the first to
-        finish.  All ranks run the same graph, so buckets form in the same order everywhere.
+        reducer.attach(all parameters)            once: completion hooks (idle until armed)
+        reducer.prepare(trainable parameters)     per phase, instead of zero_grad(): every `.grad` becomes a zeroed view
+                                                  into its bucket; autograd accumulates into it in place
+        ... backward calls ...                    `arm()` right before the one whose gradients are final (the call the
+                                                  reference synchronises on: `sync` in training/loss.py:69-152, misc.ddp_sync)
+        reducer.finish(parameters)                wait, average; parameters no backward call reached get `.grad = None`
+
+    While armed, every parameter reports from autograd's post-accumulate hook the moment its gradient is complete; when
+    the last member of a bucket has reported, the bucket's all-reduce is enqueued (asynchronously, on the backend's
+    own stream), so the exchange of the layers that finish first runs under the backward pass of the remaining
+    ones.  Buckets are cut in reverse parameter order - the order in which a backward pass completes them.  The
+    discriminator profits most: its 512-channel low-resolution weights, most of its bytes, are the first to finish.
+    All ranks run the same graph, so every rank enqueues the same buckets in the same order.
+
+    Gradients that are not views of a bucket (a caller that never called `prepare`, e.g. a phase replayed from a
+    HIP graph, whose gradients live in the graph's pool) are still exchanged by `finish` / `reducer(params)`: packed into
+    a temporary flat buffer per bucket and copied back.
     """
 
     def __init__(self, world_size, bucket_bytes=64 << 20, group=None):
@@ -157,20 +163,57 @@ class GradReducer:
         self.group = group
         self._attached = set()
         self._armed = False
-        self._bucket, self._bucket_size, self._pending, self._seen = [], 0, [], set()
+        self._plans = {}                 # tuple(id(p)) -> plan
+        self._plan = None                # the plan of the phase in progress
+        self._touched, self._reported = set(), set()
+        self._pending = []               # [(work, flat buffer, None | [loose gradient tensors])]
+        self.collectives = 0             # all-reduce calls issued so far (tests, diagnostics)
 
-    # -- after the fact ----------------------------------------------------------
-    def __call__(self, params):
+    # -- the plan of a parameter list ------------------------------------------------
+    class _Plan:
+        def __init__(self, params, bucket_bytes):
+            self.params = list(params)
+            self.buffers, self.bucket_of, self.members, self.views = [], {}, [], {}
+            order = list(reversed(self.params))            # completion order of a backward pass
+            start = 0
+            while start < len(order):
+                end, size = start, 0
+                while end < len(order) and order[end].dtype == order[start].dtype and \
+                        (end == start or size + order[end].numel() * order[end].element_size() <= bucket_bytes):
+                    size += order[end].numel() * order[end].element_size()
+                    end += 1
+                group = order[start:end]
+                flat = torch.zeros(sum(q.numel() for q in group), dtype=group[0].dtype, device=group[0].device)
+                offset = 0
+                for q in group:
+                    self.views[id(q)] = flat[offset:offset + q.numel()].view(q.shape)
+                    self.bucket_of[id(q)] = len(self.buffers)
+                    offset += q.numel()
+                self.buffers.append(flat)
+                self.members.append({id(q) for q in group})
+                start = end
+
+    def prepare(self, params):
+        """Instead of `zero_grad()` at the start of a phase: point every parameter's `.grad` into its bucket, zeroed."""
+        params = [p for p in params]
         if self.world_size <= 1:
-            return 0
-        grads = [p.grad for p in params if p.grad is not None]
-        if not grads:
-            return 0
-        for g in grads:
-            self._add(g)
-        return self._drain()
+            for p in params:
+                p.grad = None
+            return
+        key = tuple(id(p) for p in params)
+        plan = self._plans.get(key)
+        if plan is None or any(plan.views[id(p)].device != p.device for p in params):
+            plan = self._plans[key] = self._Plan(params, self.bucket_bytes)
+        for flat in plan.buffers:
+            flat.zero_()
+        for p in params:
+            p.grad = plan.views[id(p)]
+        self._plan = plan
+        self._launched = [False] * len(plan.buffers)
+        self._waiting = [set(m) for m in plan.members]
+        self._touched, self._reported = set(), set()
 
-    # -- overlapped with backward ---------------------------------------------------
+    # -- hooks -------------------------------------------------------------------------
     def attach(self, params):
         """Register the completion hook on every parameter (once; idle until `arm()`)."""
         if self.world_size <= 1:
@@ -187,54 +230,87 @@ class GradReducer:
         """The next backward call produces final gradients: exchange them as they complete."""
         if self.world_size > 1:
             self._armed = True
-            self._seen = set()
+            self._reported = set()
 
     def _on_grad_ready(self, p):
-        if self._armed and p.grad is not None:
-            self._seen.add(id(p))
-            self._add(p.grad)
+        self._touched.add(id(p))
+        if not self._armed or p.grad is None:
+            return
+        self._reported.add(id(p))
+        plan = self._plan
+        if plan is None or id(p) not in plan.views or p.grad.data_ptr() != plan.views[id(p)].data_ptr():
+            return                                    # a loose gradient: finish() packs it
+        b = plan.bucket_of[id(p)]
+        self._waiting[b].discard(id(p))
+        if not self._waiting[b] and not self._launched[b]:
+            self._launch(b)
 
+    def _all_reduce(self, flat):
+        self.collectives += 1
+        return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+
+    def _launch(self, b):
+        self._launched[b] = True
+        self._pending.append((self._all_reduce(self._plan.buffers[b]), self._plan.buffers[b], None))
+
+    # -- end of the phase -----------------------------------------------------------------
     def finish(self, params):
-        """After the armed backward call: exchange what the hooks have not covered (parameters that were
-        not attached, or whose gradient stems from an earlier call only), wait, average, unpack.  Returns
-        the bytes exchanged."""
+        """After the phase's last backward call: enqueue the buckets that are not under way yet, exchange gradients
+        that do not live in a bucket, wait, average.  Returns the bytes exchanged."""
         if self.world_size <= 1:
             return 0
-        armed, self._armed = self._armed, False
+        self._armed = False
+        plan, loose = self._plan, []
+        if plan is not None:
+            for b in range(len(plan.buffers)):
+                if not self._launched[b]:
+                    self._launch(b)
         for p in params:
-            if p.grad is not None and not (armed and id(p) in self._seen):
-                self._add(p.grad)
-        self._seen = set()
+            if p.grad is None:
+                continue
+            in_bucket = plan is not None and id(p) in plan.views and p.grad.data_ptr() == plan.views[id(p)].data_ptr()
+            if not in_bucket:
+                loose.append(p.grad)
+        self._exchange_loose(loose)
+        total = self._drain()
+        if plan is not None:
+            for p in plan.params:          # a parameter that no backward call of the phase reached has no gradient
+                if id(p) not in self._touched and p.grad is not None and p.grad.data_ptr() == plan.views[id(p)].data_ptr():
+                    p.grad = None
+        self._plan = None
+        return total
+
+    def __call__(self, params):
+        """Exchange the gradients of `params` as they are (after the backward pass, no hooks, no prepared buckets)."""
+        if self.world_size <= 1:
+            return 0
+        self._exchange_loose([p.grad for p in params if p.grad is not None])
         return self._drain()
 
-    # -- buckets -------------------------------------------------------------------
-    def _add(self, g):
-        if self._bucket and (self._bucket_size + g.numel() * g.element_size() > self.bucket_bytes or g.dtype != self._bucket[0].dtype):
-            self._flush()
-        self._bucket.append(g)
-        self._bucket_size += g.numel() * g.element_size()
-        if self._bucket_size >= self.bucket_bytes:
-            self._flush()
-
-    def _flush(self):
-        if not self._bucket:
-            return
-        bucket, self._bucket, self._bucket_size = self._bucket, [], 0
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        work = torch.distributed.all_reduce(flat, group=self.group, async_op=True)
-        self._pending.append((work, flat, bucket))
+    def _exchange_loose(self, grads):
+        start = 0
+        while start < len(grads):
+            end, size = start, 0
+            while end < len(grads) and grads[end].dtype == grads[start].dtype and \
+                    (end == start or size + grads[end].numel() * grads[end].element_size() <= self.bucket_bytes):
+                size += grads[end].numel() * grads[end].element_size()
+                end += 1
+            bucket = grads[start:end]
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            self._pending.append((self._all_reduce(flat), flat, bucket))
+            start = end
 
     def _drain(self):
-        self._flush()
         pending, self._pending = self._pending, []
         total = 0
         for work, flat, bucket in pending:
             work.wait()
             flat.div_(self.world_size)
-            offset = 0
-            for g in bucket:
-                g.copy_(flat[offset:offset + g.numel()].view_as(g))
-                offset += g.numel()
+            if bucket is not None:
+                offset = 0
+                for g in bucket:
+                    g.copy_(flat[offset:offset + g.numel()].view_as(g))
+                    offset += g.numel()
             total += flat.numel() * flat.element_size()
         return total
 
@@ -458,6 +534,8 @@ class Trainer:
             else:
                 phase.opt.zero_grad(set_to_none=True)
                 set_requires_grad(phase.module, parts=self.requires_grad_parts[phase.name])
+                if self.num_gpus > 1:     # gradients accumulate straight into the buckets that are exchanged
+                    self.reducer.prepare([p for p in phase.module.parameters() if p.requires_grad])
                 for round_idx, (r_img, r_c, g_z, g_c) in enumerate(zip(phase_real_img, phase_real_c, phase_gen_z, phase_gen_c)):
                     self.loss.accumulate_gradients(phase=phase.name, real_img=r_img, real_c=r_c, gen_z=g_z, gen_c=g_c,
                                                    sync=(round_idx == rounds - 1), gain=phase.interval)

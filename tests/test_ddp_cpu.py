@@ -7,6 +7,7 @@ import socket
 import pytest
 import torch
 import torch.multiprocessing as mp
+import torch.utils._python_dispatch
 
 
 def _free_port():
@@ -56,9 +57,25 @@ def test_grad_reducer_two_ranks_gloo(bucket_bytes):
     assert sorted(results) == [(0, True, True), (1, True, True)]
 
 
+class _CountCopies(torch.utils._python_dispatch.TorchDispatchMode):
+    """Counts the operators that would move gradient bytes around: concatenations and copies."""
+
+    def __init__(self):
+        super().__init__()
+        self.seen = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if 'aten.cat' in name or 'aten.copy_' in name or 'aten.clone' in name or 'aten._foreach_copy' in name:
+            self.seen.append(name)
+        return func(*args, **(kwargs or {}))
+
+
 def _rank_overlap(rank, world, port, bucket_bytes, result_queue):
-    """Two backward calls per phase (as Dmain: generated, then real images); the reducer is armed before the second,
-    exchanges from the post-accumulate hooks, and must end with the rank average of the accumulated gradients."""
+    """Two backward calls per phase (as Dmain: generated, then real images).  The gradients accumulate in the
+    reducer's buckets (prepare); it is armed before the second call, enqueues a bucket's all-reduce from the
+    post-accumulate hook of the bucket's last member, and must end with the rank average of the accumulated
+    gradients - with one collective per bucket and without packing or unpacking copies."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
     from ga_gan_amd.training.training_loop import GradReducer
@@ -66,38 +83,54 @@ def _rank_overlap(rank, world, port, bucket_bytes, result_queue):
     net = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
                               torch.nn.Linear(64, 3))
     frozen = torch.nn.Linear(3, 3).requires_grad_(False)   # attached while frozen, takes no part in the phase
+    unused = torch.nn.Parameter(torch.ones(5))          # trainable, prepared, but no backward call reaches it
     net.requires_grad_(False)                           # (the trainer attaches to frozen networks and enables parts per phase)
-    extra = torch.nn.Parameter(torch.ones(4))           # not attached: covered by finish()
+    extra = torch.nn.Parameter(torch.ones(4))           # not attached, not prepared: a loose gradient, covered by finish()
     reducer = GradReducer(world, bucket_bytes=bucket_bytes)
-    reducer.attach(list(net.parameters()) + list(frozen.parameters()))
+    reducer.attach(list(net.parameters()) + list(frozen.parameters()) + [unused])
     net.requires_grad_(True)
-    fired = []
-    for q in net.parameters():
-        q.register_post_accumulate_grad_hook(lambda t: fired.append(len(reducer._pending)))
     torch.manual_seed(100 + rank)
     x1, x2 = torch.randn(8, 20), torch.randn(8, 20)
+    # this rank's own gradients, from a copy of the network that the reducer does not know (the buckets are
+    # all-reduced where they lie, so after the armed backward call `.grad` may already hold the sum over ranks)
+    import copy
+    twin = copy.deepcopy(net)
+    (twin(x1).square().mean() + twin(x2).square().mean()).backward()
+    own = [q.grad.clone() for q in twin.parameters()] + [torch.full([4], float(rank + 1))]
     ok = True
-    for phase in range(2):                              # hooks stay registered from phase to phase
-        for q in list(net.parameters()) + [extra]:
-            q.grad = None
+    trainable = list(net.parameters()) + [unused]
+    nbytes = sum(q.numel() * 4 for q in trainable)
+    for phase in range(2):                              # hooks and buckets stay from phase to phase
+        extra.grad = None
+        reducer.prepare(trainable)
+        views = [q.grad for q in trainable]
+        ok &= all(float(v.abs().sum()) == 0 for v in views)
         net(x1).square().mean().backward()              # not armed: nothing is exchanged yet
-        ok &= len(reducer._pending) == 0 and not reducer._bucket
+        ok &= len(reducer._pending) == 0
+        ok &= all(q.grad.data_ptr() == v.data_ptr() for q, v in zip(trainable, views))     # accumulated in place
         local_first = [q.grad.clone() for q in net.parameters()]
-        reducer.arm()
-        (net(x2).square().mean() + (extra * (rank + 1)).sum()).backward()
-        in_flight = len(reducer._pending)               # buckets already handed to the backend during backward
+        before = reducer.collectives
+        with _CountCopies() as copies:
+            reducer.arm()
+            (net(x2).square().mean() + (extra * (rank + 1)).sum()).backward()
+            in_flight = len(reducer._pending)           # buckets already handed to the backend during backward
+            moved = reducer.finish(trainable + [extra])
         params = list(net.parameters()) + [extra]
-        local = [q.grad.clone() for q in params]
-        moved = reducer.finish(params)
         gathered = [None] * world
-        torch.distributed.all_gather_object(gathered, local)
+        torch.distributed.all_gather_object(gathered, own)
         for i, q in enumerate(params):
             mean = sum(g[i] for g in gathered) / world
-            ok &= torch.allclose(q.grad, mean, atol=1e-6)
-        ok &= moved == sum(q.numel() * 4 for q in params)
+            ok &= torch.allclose(q.grad, mean, atol=1e-5)
+        ok &= unused.grad is None                       # as if it had never been given a gradient
+        ok &= moved == nbytes + extra.numel() * 4
         ok &= all(a.abs().sum() > 0 for a in local_first)
+        buckets = len(reducer._plans[tuple(id(q) for q in trainable)].buffers)
+        ok &= buckets == (1 if bucket_bytes >= nbytes else buckets) and buckets <= -(-nbytes // bucket_bytes) + len(trainable)
+        ok &= reducer.collectives - before == buckets + 1            # + 1: the loose gradient of `extra`
+        # the only copies: packing / unpacking the ONE loose gradient (cat + copy_)
+        ok &= len(copies.seen) == 2
         if bucket_bytes < 1 << 20:
-            ok &= in_flight >= 2                        # small buckets: the exchange started before backward ended
+            ok &= buckets >= 3 and in_flight >= 2       # small buckets: the exchange started before backward ended
     ok &= all(q.grad is None for q in frozen.parameters())
     result_queue.put((rank, bool(ok)))
     torch.distributed.destroy_process_group()
@@ -116,6 +149,21 @@ def test_grad_reducer_overlapped_with_backward_two_ranks_gloo(bucket_bytes):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_grad_reducer_bucket_plan():
+    """Buckets hold whole tensors in reverse parameter order, none larger than the limit unless a single tensor is."""
+    from ga_gan_amd.training.training_loop import GradReducer
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 10, 3000, 500, 500, 20)]
+    plan = GradReducer._Plan(params, bucket_bytes=4096)
+    sizes = [b.numel() for b in plan.buffers]
+    assert sizes == [20 + 500 + 500, 3000, 10 + 1000]          # from the last parameter backwards
+    assert plan.bucket_of[id(params[5])] == 0 and plan.bucket_of[id(params[2])] == 1 and plan.bucket_of[id(params[0])] == 2
+    for p in params:
+        v = plan.views[id(p)]
+        assert v.shape == p.shape and v.is_contiguous()
+    a, b = plan.views[id(params[4])], plan.views[id(params[3])]
+    assert b.data_ptr() == a.data_ptr() + 500 * 4              # packed back to back
 
 
 def test_grad_reducer_single_rank_is_a_no_op():

@@ -127,3 +127,29 @@ def test_full_size_generator_256():
     rows = img.double().sum(dim=[0, 1, 3])
     assert golden_io.rel_err(rows, case.t('row_sums')) < 1e-4
     assert abs(float(img.double().abs().sum()) / float(case.np('abs_sum')) - 1) < 1e-5
+
+
+def test_generator_512_affine_plus_against_reference_gradients():
+    """The 512 x 512 Affine+ generator (the discriminator-heavy configuration's generator), batch 1: the oracle's
+    image and the gradient of every trainable parameter against the reference's float32 run.  The style gradients
+    are cancelling sums (ill-conditioned in float32): a tensor is held to 2e-3 or three times the reference's own
+    distance from the float64 evaluation stored beside it, whichever is larger."""
+    case = [c for c in golden_io.load('full_size_grads_more') if c.meta['tag'] == 'G512_affine_plus'][0]
+    m = case.meta
+    p = {n: seeded_fill(n, s) for n, s in zip(m['names'], m['shapes'])}
+    for k in m['trainable']:
+        p[k].requires_grad_(True)
+    cfg = sg.GeneratorConfig(img_resolution=m['res'], channel_base=m['channel_base'], conv_clamp=256, use_domain_modulation=True,
+                             domain_modulation_parametrization=m['parametrization'])
+    z = torch.randn(1, 512, generator=torch.Generator().manual_seed(m['z_seed']))
+    dy = torch.randn(1, 3, m['res'], m['res'], generator=torch.Generator().manual_seed(m['dy_seed']))
+    img = sg.generator(p, z, torch.zeros(1, 0), cfg, noise_mode='const', fused_modconv=False)
+    mid = m['res'] // 2
+    assert golden_io.rel_err(img.detach()[:, :, mid - 8:mid + 8, mid - 8:mid + 8], case.t('img_crop')) < 1e-4
+    assert golden_io.rel_err(img.detach().double().sum(dim=[0, 1, 3]), case.t('img_row_sums')) < 1e-4
+    grads = torch.autograd.grad((img * dy).sum(), [p[k] for k in m['trainable']])
+    for k, g in zip(m['trainable'], grads):
+        whole = 'g.' + k in case
+        got = g if whole else g.flatten()[::61]
+        ref, exact = case.t(('g.' if whole else 'gs.') + k), case.t(('xg.' if whole else 'xgs.') + k)
+        assert golden_io.rel_err(got, exact) < max(2e-3, 3 * golden_io.rel_err(ref, exact)), k

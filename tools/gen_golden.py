@@ -675,10 +675,49 @@ def _exact_generator_gradients(G, names, trainable, z, dy, res, channel_base, pa
     p = {n: every[n].detach().double() for n in names}
     for k in trainable:
         p[k].requires_grad_()
-    cfg = osg.GeneratorConfig(img_resolution=res, channel_base=channel_base, conv_clamp=256, use_domain_modulation=True,
-                              domain_modulation_parametrization=par)
-    img = osg.generator(p, z.double(), torch.zeros(1, 0, dtype=torch.float64), cfg, noise_mode='const')
+    cfg = osg.GeneratorConfig(img_resolution=res, channel_base=channel_base, conv_clamp=256, use_domain_modulation=par is not None,
+                              domain_modulation_parametrization=par or 'multiplicative')
+    img = osg.generator(p, z.double(), torch.zeros(1, 0, dtype=torch.float64), cfg, noise_mode='const', fused_modconv=False)
     return [g.float() for g in torch.autograd.grad((img * dy.double()).sum(), [p[k] for k in trainable])]
+
+
+def _add_generator_case(b, tag, res, channel_base, par, parts, z_seed):
+    """One full-size generator case of gen_full_size_grads / gen_full_size_grads_more.  par=None: no domain modulation."""
+    torch.manual_seed(0)
+    use_dm = par is not None
+    with quiet():
+        G = ref_networks.Generator(
+            z_dim=512, c_dim=0, w_dim=512, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=8),
+            synthesis_kwargs=dict(channel_base=channel_base, channel_max=512, num_fp16_res=0, conv_clamp=256,
+                                  use_domain_modulation=use_dm, domain_modulation_parametrization=par if use_dm else 'multiplicative',
+                                  generator_requires_grad_parts=parts))
+    names = _fill_all(G)
+    G.train()
+    ref_training_loop.set_requires_grad(G, list(parts))
+    trainable = [n for n, p in G.named_parameters() if p.requires_grad]
+    z = torch.randn(1, 512, generator=torch.Generator().manual_seed(z_seed))
+    img = G(z, torch.zeros(1, 0), noise_mode='const')
+    dy = torch.randn(img.shape, generator=torch.Generator().manual_seed(z_seed + 100))
+    grads = torch.autograd.grad((img * dy).sum(), [p for p in G.parameters() if p.requires_grad])
+    mid = res // 2
+    exact = _exact_generator_gradients(G, names, trainable, z, dy, res, channel_base, par)
+    b.add(dict(tag=tag, kind='G', res=res, channel_base=channel_base, parametrization=par if use_dm else '', use_domain_modulation=use_dm,
+               parts=parts, names=names, shapes=_shapes(G, names), trainable=trainable, z_seed=z_seed, dy_seed=z_seed + 100),
+          **_summary('img_', img, (mid - 8, mid + 8)),
+          **{k: v for n, gr in zip(trainable, grads) for k, v in _grad_entries(n, gr).items()},
+          **{'x' + k: v for n, gr in zip(trainable, exact) for k, v in _grad_entries(n, gr).items() if not k.startswith('gnorm.')})
+    print(tag, 'trainable tensors', len(trainable), 'elements', sum(int(gr.numel()) for gr in grads), flush=True)
+
+
+def gen_full_size_grads_more():
+    """Two more full-size generator cases in the layout of gen_full_size_grads (a bundle of their own, so that the
+    first one keeps its bytes): the 1024 x 1024 generator with EVERY parameter trainable (full fine-tune, no domain
+    modulation) and the 512 x 512 Affine+ generator."""
+    b = Bundle('full_size_grads_more')
+    _add_generator_case(b, 'G1024_full', 1024, 32768, None, ['all'], 7)
+    _add_generator_case(b, 'G512_affine_plus', 512, 32768, 'out_in_additive',
+                        ['synt_affine', 'tRGB_affine', 'synt_weights_offset.b64', 'tRGB_weights_offset.b64'], 8)
+    b.save()
 
 
 def gen_full_size_grads():
@@ -695,30 +734,7 @@ def gen_full_size_grads():
                ['synt_affine_weights_offset', 'tRGB_affine_weights_offset', 'synt_weights_offset.b64',
                 'tRGB_weights_offset.b64'], 6)]
     for tag, res, channel_base, par, parts, z_seed in gcases:
-        torch.manual_seed(0)
-        with quiet():
-            G = ref_networks.Generator(
-                z_dim=512, c_dim=0, w_dim=512, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=8),
-                synthesis_kwargs=dict(channel_base=channel_base, channel_max=512, num_fp16_res=0, conv_clamp=256,
-                                      use_domain_modulation=True, domain_modulation_parametrization=par,
-                                      generator_requires_grad_parts=parts))
-        names = _fill_all(G)
-        G.train()
-        ref_training_loop.set_requires_grad(G, list(parts))
-        trainable = [n for n, p in G.named_parameters() if p.requires_grad]
-        z = torch.randn(1, 512, generator=torch.Generator().manual_seed(z_seed))
-        img = G(z, torch.zeros(1, 0), noise_mode='const')
-        dy = torch.randn(img.shape, generator=torch.Generator().manual_seed(z_seed + 100))
-        grads = torch.autograd.grad((img * dy).sum(), [p for p in G.parameters() if p.requires_grad])
-        mid = res // 2
-        exact = _exact_generator_gradients(G, names, trainable, z, dy, res, channel_base, par)
-        b.add(dict(tag=tag, kind='G', res=res, channel_base=channel_base, parametrization=par, parts=parts, names=names,
-                   shapes=_shapes(G, names), trainable=trainable, z_seed=z_seed, dy_seed=z_seed + 100),
-              **_summary('img_', img, (mid - 8, mid + 8)),
-              **{k: v for n, gr in zip(trainable, grads) for k, v in _grad_entries(n, gr).items()},
-              **{'x' + k: v for n, gr in zip(trainable, exact) for k, v in _grad_entries(n, gr).items() if not k.startswith('gnorm.')})
-        print(tag, 'trainable tensors', len(trainable), 'elements', sum(int(gr.numel()) for gr in grads), flush=True)
-        del G, img, grads
+        _add_generator_case(b, tag, res, channel_base, par, parts, z_seed)
 
     for tag, res, channel_base, mbstd, n, seed in [('D256', 256, 16384, 8, 4, 21), ('D512', 512, 32768, 8, 2, 22),
                                                    ('D1024', 1024, 32768, 4, 2, 23)]:
