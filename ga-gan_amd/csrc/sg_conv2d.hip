@@ -55,7 +55,7 @@ constexpr int kPixels = 256;      // output pixels per workgroup
 constexpr int kPixelsWide = 512;  // ... of the float kernel on layers with enough pixels to fill the chip with such tiles
 constexpr int kPixelsHalf = 128;  // ... of the float kernel at stride 2, where LDS holds the footprint of 128 output pixels only
 constexpr int kThreads = 256;
-constexpr int kPitchSplit = 144;  // bytes per LDS pixel row of a float tensor split into 2 half planes: 2 x 64 + 16 pad
+constexpr int kPitchSplit = 128;  // bytes per LDS row of a float tensor split into 2 half planes (swizzled, no padding)
 constexpr int kSplitTaps = 3;     // taps of the weight chunk held in LDS at a time (split float path)
 
 __device__ __forceinline__ int floor_div_i(int a, int b);
@@ -323,38 +323,75 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         half_range_scale(t.amax, 1, 3, false, mul, inv_w);
     }
 
-    // ---- split float path: multiply the staged taps [g0, g0 + gtaps) of the weight chunk ------------------------
-    auto split_multiply = [&](const unsigned char* s_w, const unsigned char* s_in, int g0, int gtaps) {
-        for (int tl = 0; tl < gtaps; tl++) {
-            const int tap = g0 + tl;
-            const int ky = tap / ph.nkx, kx = tap - ky * ph.nkx;
-            uint4 a[M_TILES][2];
+    // ---- split float path -------------------------------------------------------------------------------------
+    // LDS images of split rows: 128 bytes per row (pixel or weight row: 2 planes x 32 channels), no padding; the
+    // 16-byte slot s of row r lives at slot s ^ ((r >> 1) & 7), which puts the 16 rows of a ds_read_b128 lane group
+    // on 16 different bank slots at any row offset (a tap shift moves all rows alike).
+    auto split_addr = [](int row, int slot) { return row * 128 + (((slot ^ (row >> 1)) & 7) << 4); };
+    int b_row[NT];            // footprint pixel of the lane's column in n-tile j, tap (0, 0)
+    int a_lane = 0;           // plane 0 of weight row lrow (rows m * 16 + lrow, tap * BM + ...: same swizzle); plane 1 at ^ 64
+    if constexpr (SPLIT) {
 #pragma unroll
-            for (int m = 0; m < M_TILES; m++)
+        for (int j = 0; j < NT; j++) b_row[j] = b_addr[j] / PITCH;
+        a_lane = split_addr(lrow, lgrp);
+    }
+    // Multiply the staged taps [g0, g0 + gtaps) of the weight chunk.  Steps (tap, n-tile) run in one fixed order; the
+    // pixel fragments of the next step and - two steps before a tap ends - the weight fragments of the next tap are
+    // read into a second register set while the 12 matrix instructions of the current step run.
+    // (the images are named by their byte offsets in smem, so that the reads stay LDS instructions)
+    auto split_multiply = [&](int w_off, int x_off, int g0, int gtaps) {
+        const unsigned char* s_w = smem + w_off;
+        const unsigned char* s_in = smem + x_off;
+        int tap_row[kSplitTaps];
 #pragma unroll
-                for (int pl = 0; pl < 2; pl++)
-                    a[m][pl] = *reinterpret_cast<const uint4*>(s_w + (tl * BM + m * 16) * PITCH + pl * 64 + a_addr);
-            const int tap_off = (ky * lw + kx) * PITCH;
+        for (int tl = 0; tl < kSplitTaps; tl++) {
+            const int tap = g0 + tl, ky = tap / ph.nkx;
+            tap_row[tl] = ky * lw + (tap - ky * ph.nkx);
+        }
+        uint4 a[2][M_TILES][2], b[2][2];
+        auto read_a = [&](int tl, uint4 (&dst)[M_TILES][2]) {
+#pragma unroll
+            for (int m = 0; m < M_TILES; m++) {
+                const unsigned char* r = s_w + (tl * BM + m * 16) * 128;
+                dst[m][0] = *reinterpret_cast<const uint4*>(r + a_lane);
+                dst[m][1] = *reinterpret_cast<const uint4*>(r + (a_lane ^ 64));
+            }
+        };
+        auto read_b = [&](int tl, int j, uint4 (&dst)[2]) {
+            const int ad = split_addr(b_row[j] + tap_row[tl], lgrp);
+            dst[0] = *reinterpret_cast<const uint4*>(s_in + ad);
+            dst[1] = *reinterpret_cast<const uint4*>(s_in + (ad ^ 64));
+        };
+        read_a(0, a[0]);
+        read_b(0, 0, b[0]);
+#pragma unroll
+        for (int tl = 0; tl < kSplitTaps; tl++) {
+            if (tl >= gtaps) break;
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                uint4 b[2];
+                constexpr int kAhead = NT >= 2 ? NT - 2 : 0;          // the step that fetches the next tap's weights
+                const int step = tl * NT + j;
+                if (j + 1 < NT) read_b(tl, j + 1, b[(step + 1) & 1]);
+                else if (tl + 1 < gtaps) read_b(tl + 1, 0, b[(step + 1) & 1]);
+                if (j == kAhead && tl + 1 < gtaps) read_a(tl + 1, a[(tl + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);                    // (reads first: they have the whole step to land)
 #pragma unroll
-                for (int pl = 0; pl < 2; pl++) b[pl] = *reinterpret_cast<const uint4*>(s_in + b_addr[j] + tap_off + pl * 64);
-#pragma unroll
-                for (int m = 0; m < M_TILES; m++) {
-                    mma_split(a[m], b, acc[m][j]);
-                }
+                for (int m = 0; m < M_TILES; m++) mma_split(a[tl & 1][m], b[step & 1], acc[m][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
 
     if constexpr (SPLIT) {
-        // Float path: both operands come as split rows (sg_absmax.h) - per pixel (or weight row) and chunk of 32
-        // channels 128 contiguous bytes, the LDS row without its padding - so staging is 16-byte copies.  A pipeline
-        // over (chunk, tap group) stages: the global loads of the next stage - kSplitTaps taps of weights, and the
-        // input footprint when a new chunk begins - are issued into registers before the multiplies of the current
-        // one and written to LDS after them.
-        constexpr int W_IT = (kSplitTaps * BM * 8 + THREADS - 1) / THREADS;   // 16-byte pieces per lane
+        // Both operands come as split rows (sg_absmax.h): per pixel (or weight row) and chunk of 32 channels 128
+        // contiguous bytes, the LDS row.  A pipeline over (chunk, tap group) stages.  The weights of the next stage
+        // (kSplitTaps taps) go from global memory straight into the LDS buffer the current stage does not read
+        // (global_load_lds: no staging registers, no LDS write instructions; a lane's LDS destination is fixed by
+        // its position in the wave, so the swizzle is applied by choosing which 16 bytes it fetches).  The footprint
+        // of the next chunk is requested into registers at the first stage of the current one and written - to a
+        // second footprint buffer when LDS has room for it (t.x_double), else after one more barrier - at its last.
+        constexpr int W_PIECES = kSplitTaps * BM * 8;                         // 16-byte pieces of a weight stage
+        constexpr int W_IT = (W_PIECES + THREADS - 1) / THREADS;              // ... per lane
         constexpr int X_IT = PX == kPixels ? 8 : 10;                          // input pieces per lane held in registers
         const unsigned char* __restrict__ xs = t.xs;
         const unsigned char* __restrict__ ws = t.ws + (ph.w_offset / p.ci) * (int64_t)128;   // (this phase's first row)
@@ -362,34 +399,34 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         const int64_t x_plane8 = (int64_t)p.h * p.w_in * 8;   // 16-byte units from one chunk of a sample to the next
         const int chunks = t.chunks, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
         const int cb_begin = ksplit * chunks_per_split, cb_end = min(chunks, cb_begin + chunks_per_split);
-        uint4 wreg_a[W_IT], wreg_b[W_IT], xreg[X_IT];
-        auto w_load = [&](uint4 (&wreg)[W_IT], int cb, int g0) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // weights: LDS piece e = tid + k THREADS is slot e & 7 of row e >> 3 = (tap in stage) * BM + channel
+        int w_rel[W_IT], w_tl[W_IT];       // source offset from the stage's first row; tap in stage (kSplitTaps: none)
+#pragma unroll
+        for (int k = 0; k < W_IT; k++) {
+            const int e = tid + k * THREADS, row = e >> 3, o = row % BM, tl = row / BM;
+            const int piece = ((e & 7) ^ (row >> 1)) & 7;
+            w_tl[k] = (e < W_PIECES && m0 + o < p.co) ? tl : kSplitTaps;
+            w_rel[k] = (tl * p.co + m0 + o) * 128 + piece * 16;
+        }
+        auto w_issue = [&](int cb, int g0, int w_off) {
             const int gtaps = min(kSplitTaps, taps - g0);
+            const unsigned char* base = ws + ((int64_t)cb * t.w_rows + (int64_t)g0 * p.co) * 128;
 #pragma unroll
             for (int k = 0; k < W_IT; k++) {
-                const int e = tid + k * THREADS;
-                const int piece = e & 7, row = e >> 3;
-                const int o = row % BM, tap = g0 + row / BM;
-                wreg[k] = make_uint4(0, 0, 0, 0);
-                if (cb < cb_end && e < gtaps * BM * 8 && m0 + o < p.co)
-                    wreg[k] = *reinterpret_cast<const uint4*>(ws + ((int64_t)cb * t.w_rows + (int64_t)tap * p.co + m0 + o) * 128 + piece * 16);
+                if (w_tl[k] < gtaps)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + w_rel[k]),
+                                                     (__attribute__((address_space(3))) void*)(smem + w_off + (k * THREADS + wave_u * 64) * 16),
+                                                     16, 0, 0);
             }
         };
-        auto w_commit = [&](const uint4 (&wreg)[W_IT], unsigned char* s_w, int g0) {
-            const int gtaps = min(kSplitTaps, taps - g0);
-#pragma unroll
-            for (int k = 0; k < W_IT; k++) {
-                const int e = tid + k * THREADS;
-                if (e < gtaps * BM * 8) *reinterpret_cast<uint4*>(s_w + (e >> 3) * PITCH + (e & 7) * 16) = wreg[k];
-            }
-        };
-        // Where piece e of the footprint lies in the split tensor, in 16-byte units for chunk 0 (-1: outside the
-        // tensor, zero).  The same for every chunk, so the divisions are done once per lane.
+        // Where piece e of the footprint image comes from in the split tensor, in 16-byte units for chunk 0 (-1:
+        // outside the tensor, zero).  The same for every chunk, so the divisions are done once per lane.
         // (the wide tile keeps the offsets in 32 bits - the host picks it for tensors below 2^31 such units only)
         using XOff = typename std::conditional<PX == kPixels, int64_t, int>::type;
         auto x_where = [&](int e) -> XOff {
-            const int piece = e & 7;
-            int pix = e >> 3;
+            const int row = e >> 3, piece = ((e & 7) ^ (row >> 1)) & 7;
+            int pix = row;
             const int rx = pix % lw; pix /= lw;
             const int ry = pix % lh;
             const int ri = pix / lh;
@@ -398,6 +435,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
             return (XOff)((((int64_t)n * chunks * p.h + iy) * p.w_in + ix) * 8 + piece);
         };
         XOff xoff[X_IT];
+        uint4 xreg[X_IT];
 #pragma unroll
         for (int k = 0; k < X_IT; k++) xoff[k] = x_where(tid + k * THREADS);
         auto x_fetch = [&](int cb, XOff where) -> uint4 {   // (no branch: a piece outside is read at the tensor's start and dropped)
@@ -408,11 +446,12 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
 #pragma unroll
             for (int k = 0; k < X_IT; k++) xreg[k] = x_fetch(cb, xoff[k]);
         };
-        auto x_commit = [&](unsigned char* s_in, int cb) {
+        auto x_commit = [&](int x_off, int cb) {
+            unsigned char* s_in = smem + x_off;
 #pragma unroll
             for (int k = 0; k < X_IT; k++) {
                 const int e = tid + k * THREADS;
-                if (e < x_items) *reinterpret_cast<uint4*>(s_in + (e >> 3) * PITCH + (e & 7) * 16) = xreg[k];
+                if (e < x_items) *reinterpret_cast<uint4*>(s_in + e * 16) = xreg[k];
             }
             for (int e0 = X_IT * THREADS + tid; e0 < x_items; e0 += 4 * THREADS) {   // (footprints beyond the register window)
                 uint4 v[4];
@@ -421,60 +460,47 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int e = e0 + u * THREADS;
-                    if (e < x_items) *reinterpret_cast<uint4*>(s_in + (e >> 3) * PITCH + (e & 7) * 16) = v[u];
+                    if (e < x_items) *reinterpret_cast<uint4*>(s_in + e * 16) = v[u];
                 }
             }
         };
-        // Stage = (chunk, tap group).  The weights of a stage are requested two stages ahead (two register sets
-        // used in turn) and written to the LDS buffer the current stage does not read, after its multiplies; the
-        // footprint of the next chunk is requested at the first stage of the current one and written - to a second
-        // footprint buffer when LDS has room for it (t.x_double), else after one more barrier - at its last stage.
-        // One barrier per stage: a wave's LDS writes and address arithmetic overlap the other waves' multiplies.
         auto advance = [&](int& cb, int& g0) {
             g0 += kSplitTaps;
             if (g0 >= taps) { g0 = 0; cb++; }
         };
-        const size_t x_bytes = (size_t)t.imgs * t.lh * t.lw * PITCH, w_bytes = (size_t)min(t.max_taps, kSplitTaps) * BM * PITCH;
-        unsigned char* s_x[2] = {smem, smem + (t.x_double ? x_bytes : 0)};
-        unsigned char* s_wb[2] = {smem + (t.x_double ? 2 : 1) * x_bytes, smem + (t.x_double ? 2 : 1) * x_bytes + w_bytes};
+        // every lane's copies into LDS have landed (then a barrier, then the reads)
+        auto copies_landed = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        const int x_bytes = t.imgs * t.lh * t.lw * PITCH, w_bytes = min(t.max_taps, kSplitTaps) * BM * PITCH;
+        const int x_second = t.x_double ? x_bytes : 0, w_first = (t.x_double ? 2 : 1) * x_bytes;
+        auto s_x = [&](int cb) { return (cb & 1) ? x_second : 0; };            // byte offsets in smem
+        auto s_wb = [&](int stage) { return w_first + ((stage & 1) ? w_bytes : 0); };
         int cb = cb_begin, g0 = 0;          // the stage being multiplied
-        int cb1 = cb, g1 = g0;              // one and two stages ahead
+        int cb1 = cb, g1 = g0;              // the stage after it
         advance(cb1, g1);
-        int cb2 = cb1, g2 = g1;
-        advance(cb2, g2);
         int sidx = 0;                       // stage counter: picks the weight buffer
         if (cb < cb_end) {
-            w_load(wreg_a, cb, g0);
+            w_issue(cb, g0, s_wb(0));
             x_load(cb);
-            w_load(wreg_b, cb1, g1);
-            x_commit(s_x[cb & 1], cb);
-            w_commit(wreg_a, s_wb[0], g0);
+            x_commit(s_x(cb), cb);
+            copies_landed();
             __syncthreads();
         }
-        // On entry the LDS buffer sidx & 1 holds this stage's weights, `next` holds (or awaits) those of the stage
-        // after it and `far` is free: it receives the request for two stages on.
-        auto stage = [&](uint4 (&next)[W_IT], uint4 (&far)[W_IT]) {
+        // One barrier per stage (two where a single footprint buffer is rewritten).  The weight buffer that receives
+        // the next stage was last read in the stage before this one, which every wave has left.
+        while (cb < cb_end) {
             const bool first = g0 == 0, last = cb1 != cb;
-            w_load(far, cb2, g2);
+            if (cb1 < cb_end) w_issue(cb1, g1, s_wb(sidx + 1));
             if (first && cb + 1 < cb_end) x_load(cb + 1);
-            split_multiply(s_wb[sidx & 1], s_x[cb & 1], g0, min(kSplitTaps, taps - g0));
-            if (cb1 < cb_end) {
-                w_commit(next, s_wb[(sidx + 1) & 1], g1);
-                if (last) {
-                    if (!t.x_double) __syncthreads();   // every wave has read the footprint of this chunk
-                    x_commit(s_x[cb1 & 1], cb1);
-                }
+            split_multiply(s_wb(sidx), s_x(cb), g0, min(kSplitTaps, taps - g0));
+            if (last && cb1 < cb_end) {
+                if (!t.x_double) __syncthreads();   // every wave has read the footprint of this chunk
+                x_commit(s_x(cb1), cb1);
             }
+            copies_landed();
             __syncthreads();
             cb = cb1; g0 = g1;
-            cb1 = cb2; g1 = g2;
-            advance(cb2, g2);
+            advance(cb1, g1);
             sidx++;
-        };
-        while (cb < cb_end) {
-            stage(wreg_b, wreg_a);
-            if (cb >= cb_end) break;
-            stage(wreg_a, wreg_b);
         }
     }
     const int chunks = (p.ci + KCH - 1) / KCH, chunks_per_split = (chunks + t.split_k - 1) / t.split_k;
@@ -758,9 +784,12 @@ Tile make_tile_of(const sg_conv2d_params& p, int px, int* out_max_taps) {
     if (balance && AH > t.th) t.th = (AH + (AH + t.th - 1) / t.th - 1) / ((AH + t.th - 1) / t.th);
     t.lw = (t.tw - 1) * p.in_step + max_nkx;
     if (split) {
-        // Rows of 144 bytes: pick the rows x images per tile that fill the most pixel slots within the LDS budget
+        // Rows of 128 bytes: pick the rows x images per tile that fill the most pixel slots within the LDS budget
         // (slots beyond imgs * th * tw idle).  Tiles that feed the per-image reduction keep whole 16-pixel groups.
-        const size_t budget = 152 * 1024 / pitch - 2 * (size_t)min(max_taps, kSplitTaps) * 64;   // (two weight buffers)
+        // (696 rows beside the two weight buffers: with more, the up-sampling layers get tiles of more images and
+        // fewer rows, whose larger share of halo rows costs more than the fuller slots return: 0.75 against 0.55 ms
+        // at 512 -> 512, 32^2 -> 64^2, batch 16)
+        const size_t budget = 152 * 1024 / 144 - 2 * (size_t)min(max_taps, kSplitTaps) * 64;
         int best_th = 1, best_imgs = 1, best_used = 0;
         for (int th = t.th; th >= 1; th = (th > 1) ? (th + 1) / 2 : 0) {
             if (!exact && (t.tw * th) % 16 != 0) break;
