@@ -26,7 +26,9 @@ __global__ void __launch_bounds__(64) absmax_reset_kernel(unsigned* slot) {
 }
 
 // blockIdx.y: which tensor; the blocks of a row stride over the tensor's 16-byte packets (and its ragged ends).
-__global__ void __launch_bounds__(256) absmax_kernel(FourTensors t, unsigned* slot) {
+// `clear`: the slot of the stream's next call, zeroed here so that that call needs no launch for it.
+__global__ void __launch_bounds__(256) absmax_kernel(FourTensors t, unsigned* slot, unsigned* clear) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) clear[threadIdx.x] = 0u;
     const int which = blockIdx.y;
     const float* __restrict__ x = t.ptr[which];
     const int64_t n = t.count[which];
@@ -219,16 +221,37 @@ int split_rows(hipStream_t stream, const float* w, int64_t rows, int c, const un
 
 int absmax_measure(hipStream_t stream, const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc,
                    const float* d, int64_t nd, const unsigned** slot) {
-    static std::atomic<unsigned> next{0};
+    // A call's measuring kernel zeroes the slot that the next call on the same stream will take, so a run of calls
+    // on one stream launches no kernel to reset slots.  The reset kernel remains for a call whose slot was not
+    // prepared that way: the first on a device, one on another stream than the call before it, and any call under
+    // stream capture (a replayed graph finds the slots as its previous replay left them).
+    struct Prepared { hipStream_t stream; unsigned slot; bool valid; };
+    static std::mutex mutex;
+    static Prepared prepared[kMaxDevices];
+    static unsigned next = 0;
     unsigned* ring = ring_of_current_device();
     if (ring == nullptr) return fail((int)hipErrorInvalidSymbol, "absmax: cannot resolve the slot ring on the current device");
-    unsigned* s = ring + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kSlots) * 4;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone;
+    unsigned idx, following;
+    bool reset;
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        idx = next++ % kSlots;
+        following = (idx + 1) % kSlots;
+        Prepared& p = prepared[dev];
+        reset = capturing || !p.valid || p.stream != stream || p.slot != idx;
+        p = Prepared{stream, following, !capturing};
+    }
+    unsigned* s = ring + (size_t)idx * 4;
     FourTensors t{{a, b, c, d}, {a ? na : 0, b ? nb : 0, c ? nc : 0, d ? nd : 0}};
     int64_t longest = 0;
     for (int i = 0; i < 4; i++) longest = std::max(longest, t.count[i]);
     const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((longest / 4 + 1023) / 1024, 1), 1024);
-    hipLaunchKernelGGL(absmax_reset_kernel, dim3(1), dim3(64), 0, stream, s);
-    hipLaunchKernelGGL(absmax_kernel, dim3(blocks, 4), dim3(256), 0, stream, t, s);
+    if (reset) hipLaunchKernelGGL(absmax_reset_kernel, dim3(1), dim3(64), 0, stream, s);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks, 4), dim3(256), 0, stream, t, s, ring + (size_t)following * 4);
     *slot = s;
     return check_launch("absmax");
 }

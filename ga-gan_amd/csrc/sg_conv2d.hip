@@ -754,7 +754,6 @@ int ilog2(int v) {
 // whose shuffle groups need tiles of whole 16-pixel groups.
 Tile make_tile_of(const sg_conv2d_params& p, int px, int* out_max_taps) {
     const bool split = p.dtype == SG_F32;   // LDS rows and weight-chunk rows of the kernel that runs this dtype
-    const size_t pitch = split ? kPitchSplit : kPitch;
     int AH = 0, AW = 0, max_taps = 0, max_nky = 0, max_nkx = 0;
     for (int i = 0; i < p.num_phases; i++) {
         const sg_conv2d_phase& ph = p.phase[i];

@@ -17,6 +17,7 @@ deliberate:
 There is no CPU path: every op refuses CPU tensors.
 """
 import math
+import os
 import re
 
 import numpy as np
@@ -27,6 +28,7 @@ from ..torch_utils import misc
 from ..torch_utils.ops import bias_act
 from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import fma
+from ..torch_utils.ops import styles as styles_op
 from ..torch_utils.ops import fused_layer
 from ..torch_utils.ops import minibatch_std
 from ..torch_utils.ops import upfirdn2d
@@ -286,7 +288,7 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
 
 @misc.profiled_function
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
-                     flip_weight=True, fused_modconv=True):
+                     flip_weight=True, fused_modconv=True, dcoefs=None):
     """Weight-modulated (and demodulated) convolution; arguments as the reference's
     `modulated_conv2d` (training/networks.py:591-668).
 
@@ -304,8 +306,9 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         weight = weight * (1 / np.sqrt(in_channels * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
 
-    dcoefs = None
-    if demodulate:   # rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + eps) without the [N,O,I,k,k] intermediate
+    if not demodulate:
+        dcoefs = None
+    elif dcoefs is None or x.dtype == torch.float16:   # rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + eps) without the [N,O,I,k,k] intermediate
         dcoefs = _demodulation(styles, weight)
 
     if not fused_modconv:
@@ -404,16 +407,41 @@ def _cast(weight, dtype):
     return memo.memo(weight, ('cast', dtype), lambda: weight.to(dtype))
 
 
+FUSE_STYLES = os.environ.get('SG_FUSE_STYLES', '1') != '0'    # (off: the framework's operators, for timing the difference)
+
+
+def _layer_styles(layer, w, weight_gain, demod_weight, kwargs):
+    """(styles, demodulation coefficients or None) of a modulated layer from its row `w` of the latent codes.
+
+    A layer without style-space offsets or edits gets both from one operator (torch_utils/ops/styles.py) that reads
+    the affine layer's parameters as they are stored; `demod_weight` is the convolution weight whose squared sums the
+    coefficients need (None: the caller does not demodulate, or computes the coefficients itself).  Every other case
+    goes through w_to_s, and the caller derives the coefficients."""
+    plain = (FUSE_STYLES and not kwargs and w.is_cuda and w.dtype == torch.float32
+             and (not layer.use_domain_modulation or layer.domain_modulation_parametrization is None))
+    if not plain:
+        return w_to_s(layer, w=w, weight_gain=weight_gain, **kwargs), None
+    affine = layer.affine
+    if getattr(affine, 'affine_weights_domain_modulation_parametrization', None) is None:
+        a, a_gain = affine.weight, affine.weight_gain
+    else:
+        a, a_gain = memo.derived(affine, ('w', w.dtype), weight_sources(affine),
+                                 lambda: weight_to_weight(affine, affine.weight.to(w.dtype)) * affine.weight_gain), 1.0
+    wsq_t = None
+    if demod_weight is not None:
+        wsq_t = memo.memo(demod_weight, 'wsq^T dense', lambda: demod_weight.square().sum(dim=[2, 3]).t().contiguous())
+    return styles_op.styles(w, a, affine.bias, wsq_t, a_gain=a_gain, b_gain=affine.bias_gain, gain=weight_gain)
+
+
 def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding, resample_filter, demodulate,
-                     flip_weight, act, gain, clamp):
+                     flip_weight, act, gain, clamp, dcoefs=None):
     """Training-path modulated convolution + bias/activation as one fused layer (same arithmetic as
     `modulated_conv2d(..., fused_modconv=False)` followed by `bias_act`, without the intermediates)."""
     out_channels, in_channels, kh, kw = weight.shape
     if x.dtype == torch.float16 and demodulate:   # keep float16 products in range
         weight = weight * (1 / np.sqrt(in_channels * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
-    dcoefs = None
-    if demodulate:
+    if demodulate and (dcoefs is None or x.dtype == torch.float16):
         dcoefs = _demodulation(styles, weight)
     return fused_layer.conv_layer(x, _cast(weight, x.dtype), f=resample_filter, up=up, padding=padding, flip_weight=flip_weight,
                                   styles=styles, dcoefs=dcoefs, noise=noise, noise_strength=noise_strength,
@@ -572,8 +600,8 @@ class SynthesisLayer(torch.nn.Module):
         assert noise_mode in ['random', 'const', 'none']
         in_resolution = self.resolution // self.up
         misc.assert_shape(x, [None, self.weight.shape[1], in_resolution, in_resolution])
-        styles = w_to_s(self, w=w, weight_gain=1.0, **kwargs)
         weight = memo.derived(self, 'weight', weight_sources(self), lambda: weight_to_weight(self, self.weight))
+        styles, dcoefs = _layer_styles(self, w, 1.0, weight if x.dtype != torch.float16 else None, kwargs)
         bias = memo.derived(self, ('b', x.dtype), [self.bias], lambda: self.bias.to(x.dtype))
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         if (FUSE_LAYERS and not fused_modconv and self.activation in ('linear', 'lrelu')
@@ -585,7 +613,7 @@ class SynthesisLayer(torch.nn.Module):
                 unit = self.noise_const
             return _modulated_layer(x, weight, styles, unit, self.noise_strength if unit is not None else None,
                                     bias, self.up, self.padding, self.resample_filter, True,
-                                    (self.up == 1), self.activation, self.act_gain * gain, act_clamp)
+                                    (self.up == 1), self.activation, self.act_gain * gain, act_clamp, dcoefs=dcoefs)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
@@ -593,7 +621,7 @@ class SynthesisLayer(torch.nn.Module):
             noise = self.noise_const * self.noise_strength
         x = modulated_conv2d(x=x, weight=weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1),
-                             fused_modconv=fused_modconv)
+                             fused_modconv=fused_modconv, dcoefs=dcoefs)
         return bias_act.bias_act(x, bias, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
 
 
@@ -616,7 +644,7 @@ class ToRGBLayer(torch.nn.Module):
         self.layer_idx = None
 
     def forward(self, x, w, fused_modconv=True, noise_mode='random', **kwargs):
-        styles = w_to_s(self, w=w, weight_gain=self.weight_gain, **kwargs)
+        styles, _ = _layer_styles(self, w, self.weight_gain, None, kwargs)
         weight = memo.derived(self, 'weight', weight_sources(self), lambda: weight_to_weight(self, self.weight))
         bias = memo.derived(self, ('b', x.dtype), [self.bias], lambda: self.bias.to(x.dtype))
         if FUSE_LAYERS and not fused_modconv and fused_layer.supported(x, _cast(weight, x.dtype), 1, 1):

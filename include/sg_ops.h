@@ -104,6 +104,44 @@ int sg_planes_segments(int dtype, int64_t pixels);
 int sg_scale_planes(const void* x, const float* s, void* y, int dtype, int64_t planes, int64_t pixels, sg_stream_t stream);
 int sg_dot_planes(const void* a, const void* b, float* part, int dtype, int64_t planes, int64_t pixels, sg_stream_t stream);
 
+/* Styles and demodulation coefficients of one modulated layer from its row of the latent codes:
+ *   styles[n, c] = gain * (a_gain * sum_k w[n, k] a[c, k] + b_gain * b[c])
+ *   dcoefs[n, o] = rsqrt(sum_c styles[n, c]^2 * wsq_t[c, o] + eps)          (only when wsq_t and dcoefs are given)
+ * All float32.  w [n, k] with w_stride elements between rows (a column of ws [n, num_ws, k] is passed as it lies);
+ * a [c, k] and b [c] are the affine layer's parameters as stored, its run-time gains in a_gain / b_gain; wsq_t [c, o]
+ * holds the sum over the taps of the squared convolution weights, transposed.  This is `styles = self.affine(w) *
+ * weight_gain` of the reference's w_to_s (DissimilarDomains/training/networks.py:502, with FullyConnectedLayer.forward,
+ * :680-700, for the gains) and the demodulation coefficients of modulated_conv2d (:631-636) written as a product with
+ * sum_k W^2 instead of over the [N, O, I, k, k] tensor.  k and o must be multiples of 4, a and wsq_t 16-byte aligned. */
+typedef struct sg_styles_params {
+    const float* w;
+    const float* a;
+    const float* b;        /* may be NULL */
+    const float* wsq_t;    /* may be NULL */
+    float a_gain, b_gain, gain, eps;
+    int32_t n, k, c, o;
+    int64_t w_stride;
+    float* styles;         /* [n, c] */
+    float* dcoefs;         /* [n, o] or NULL */
+} sg_styles_params;
+int sg_styles(const sg_styles_params* p, sg_stream_t stream);
+
+/* Gradients of sg_styles, given dstyles [n, c] and ddcoefs [n, o] (either may be NULL = zero); `f` as in the forward
+ * call with styles and dcoefs holding its results.  t [n, c] receives the whole gradient with respect to the styles
+ * (workspace, always written); dw [n, k], da [c, k], db [c] and dwsq_t [c, o] are written where given.  What autograd
+ * derives from the reference's expressions above, in two launches. */
+typedef struct sg_styles_bwd_params {
+    sg_styles_params f;
+    const float* dstyles;
+    const float* ddcoefs;
+    float* t;
+    float* dw;
+    float* da;
+    float* db;
+    float* dwsq_t;
+} sg_styles_bwd_params;
+int sg_styles_backward(const sg_styles_bwd_params* p, sg_stream_t stream);
+
 /* Layer epilogue applied to a value v produced for sample n, channel c, pixel (oy, ox):
  *   clamp(act(v * scale[n,c] + noise[n,oy,ox] * *noise_gain + bias[c]) * gain)
  * scale [n, channels], noise [.., oh, ow] (noise_stride_n elements between samples, 0 = shared) and

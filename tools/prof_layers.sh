@@ -14,3 +14,5 @@ python3 tools/layer_traffic.py /tmp/lf /tmp/lw sg:: > gpurun_out/${TAG:-r3}_laye
 timeout -s KILL 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d /tmp/ls -o p -- python3 tools/layer_bench_1024.py > /tmp/ls.log 2>&1
 python3 tools/summarize_sq.py $(ls /tmp/ls/*/*counter_collection.csv /tmp/ls/*counter_collection.csv 2>/dev/null | head -1) sg:: > gpurun_out/${TAG:-r3}_layer1024_sq_counters.json
 tail -9 gpurun_out/${TAG:-r3}_layer1024.txt
+timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/lc -o p -- python3 tools/layer_bench_1024.py > /tmp/lc.log 2>&1
+python3 tools/summarize_clock.py /tmp/lc sg:: > gpurun_out/${TAG:-r3}_layer1024_clock.json
