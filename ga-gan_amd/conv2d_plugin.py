@@ -62,6 +62,9 @@ class Plan:
     def _pack(self, w, transposed_layout):
         if transposed_layout:
             w = w.transpose(0, 1)
+        if (w.is_cuda and w.dtype in _lib.DTYPES and w.dtype != torch.float64 and len(self.phases) <= 4
+                and all(ph[4] <= PACK_MAX_TAPS and ph[5] <= PACK_MAX_TAPS for ph in self.phases)):
+            return self._pack_kernel(w)
         parts = []
         for (_, _, _, _, nky, nkx, ky_idx, kx_idx) in self.phases:
             sel, flips = w, []
@@ -73,6 +76,40 @@ class Plan:
                 sel = sel.flip(flips)
             parts.append(sel.permute(2, 3, 0, 1).reshape(-1))
         return torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
+
+
+PACK_MAX_TAPS = 8   # SG_PACK_MAX_TAPS of include/sg_ops.h
+
+
+class PackPhase(ctypes.Structure):
+    _fields_ = [('nky', ctypes.c_int32), ('nkx', ctypes.c_int32), ('ky', ctypes.c_int32 * PACK_MAX_TAPS), ('kx', ctypes.c_int32 * PACK_MAX_TAPS)]
+
+
+class PackParams(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p), ('dtype', ctypes.c_int32), ('co', ctypes.c_int32), ('ci', ctypes.c_int32),
+                ('stride_o', ctypes.c_int64), ('stride_i', ctypes.c_int64), ('stride_y', ctypes.c_int64), ('stride_x', ctypes.c_int64),
+                ('num_phases', ctypes.c_int32), ('phase', PackPhase * 4)]
+
+
+def _pack_kernel(self, w):
+    """`Plan._pack` as one launch of sg_pack_weights (w may be any strided view)."""
+    co, ci = w.shape[0], w.shape[1]
+    total = sum(ph[4] * ph[5] for ph in self.phases) * co * ci
+    out = torch.empty([total], dtype=w.dtype, device=w.device)
+    p = PackParams(w.data_ptr(), out.data_ptr(), _lib.dtype_code(w), co, ci, w.stride(0), w.stride(1), w.stride(2), w.stride(3),
+                   len(self.phases))
+    for k, (_, _, _, _, nky, nkx, ky_idx, kx_idx) in enumerate(self.phases):
+        p.phase[k].nky, p.phase[k].nkx = nky, nkx
+        for t, v in enumerate(ky_idx):
+            p.phase[k].ky[t] = v
+        for t, v in enumerate(kx_idx):
+            p.phase[k].kx[t] = v
+    fn = _lib.lib().sg_pack_weights
+    _lib.launch_raw(lambda stream: fn(ctypes.byref(p), stream), w, 'sg_pack_weights', 'pack_weights_kernel', 2 * _lib.nbytes(out))
+    return out
+
+
+Plan._pack_kernel = _pack_kernel
 
 
 def _take(w, dim, idx):

@@ -104,6 +104,28 @@ int sg_planes_segments(int dtype, int64_t pixels);
 int sg_scale_planes(const void* x, const float* s, void* y, int dtype, int64_t planes, int64_t pixels, sg_stream_t stream);
 int sg_dot_planes(const void* a, const void* b, float* part, int dtype, int64_t planes, int64_t pixels, sg_stream_t stream);
 
+/* Packs a convolution weight w [co][ci][kh][kw] (element strides stride_o / stride_i / stride_y / stride_x: a
+ * conv_transpose2d weight [ci][co][kh][kw] is passed with the first two exchanged) into the flat
+ * [phase][tap row][tap column][co][ci] tensor that sg_conv2d reads (its `w`, with `phase[i].w_offset` = the element
+ * offset of phase i): tap (ty, tx) of phase i is w[.][.][ky[ty]][kx[tx]].  One launch; same dtype in and out.  It stands
+ * for what the reference leaves to cuDNN's own filter transformation behind conv2d / conv_transpose2d
+ * (torch_utils/ops/conv2d_gradfix.py:48-61) plus the `w.flip([2, 3])` of conv2d_resample.py:28-31. */
+#define SG_PACK_MAX_TAPS 8
+typedef struct sg_pack_phase {
+    int32_t nky, nkx;
+    int32_t ky[SG_PACK_MAX_TAPS], kx[SG_PACK_MAX_TAPS];
+} sg_pack_phase;
+typedef struct sg_pack_params {
+    const void* w;
+    void* out;
+    int32_t dtype;
+    int32_t co, ci;
+    int64_t stride_o, stride_i, stride_y, stride_x;
+    int32_t num_phases;
+    sg_pack_phase phase[4];
+} sg_pack_params;
+int sg_pack_weights(const sg_pack_params* p, sg_stream_t stream);
+
 /* Styles and demodulation coefficients of one modulated layer from its row of the latent codes:
  *   styles[n, c] = gain * (a_gain * sum_k w[n, k] a[c, k] + b_gain * b[c])
  *   dcoefs[n, o] = rsqrt(sum_c styles[n, c]^2 * wsq_t[c, o] + eps)          (only when wsq_t and dcoefs are given)

@@ -340,3 +340,27 @@ def test_conv2d_transposed_padded_rows(shape, dtype):
     assert y.shape == (n, co, oh, ow_pad)
     close(y[..., :ow], want, 2 * ULP[dtype], 'valid part')
     assert float(y[..., ow:].abs().max()) == 0, 'padding columns must be zero'
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_pack_weights_kernel_matches_composition(dtype):
+    """sg_pack_weights against the same packing composed from slices, flips, permuting copies and a concatenation,
+    for plain, strided and polyphase-transposed plans, dense and transposed weight views: bit-exact."""
+    from ga_gan_amd import conv2d_plugin as cp
+    g = torch.Generator().manual_seed(3)
+    for co, ci, k in ((5, 7, 3), (64, 32, 3), (3, 16, 1), (8, 8, 5)):
+        w = torch.randn(co, ci, k, k, generator=g).to(DEV).to(dtype)
+        plans = [cp.plan_conv(k, k, padding=k // 2), cp.plan_conv(k, k, stride=2, padding=0)]
+        if k > 1:
+            plans.append(cp.plan_conv_transpose(k, k, stride=2, padding=0))
+        for plan in plans:
+            for transposed in (False, True):
+                got = plan._pack(w, transposed)
+                src = w.transpose(0, 1) if transposed else w
+                parts = []
+                for (_, _, _, _, nky, nkx, ky_idx, kx_idx) in plan.phases:
+                    sel = src[:, :, list(ky_idx)][:, :, :, list(kx_idx)]
+                    parts.append(sel.permute(2, 3, 0, 1).reshape(-1))
+                want = torch.cat(parts)
+                assert got.dtype == dtype and got.shape == want.shape
+                assert torch.equal(got, want), (co, ci, k, plan.kind, transposed)
