@@ -18,7 +18,8 @@ SYMBOLS = ('sg_version', 'sg_last_error', 'sg_init', 'sg_upfirdn2d_out_size', 's
            'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask',
            'sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes', 'sg_conv_up2_fir', 'sg_conv_up2_fir_supported',
            'sg_upfirdn2d_add', 'sg_upfirdn2d_add_supported', 'sg_upfirdn2d_kernel', 'sg_planes_segments', 'sg_scale_planes', 'sg_dot_planes',
-           'sg_styles', 'sg_styles_backward', 'sg_pack_weights')
+           'sg_styles', 'sg_styles_backward', 'sg_pack_weights',
+           'sg_conv2d_prepared_weight_bytes', 'sg_conv2d_prepare_weights')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -87,7 +88,8 @@ def lib():
         for name in ('sg_conv2d', 'sg_conv2d_wgrad', 'sg_epilogue_backward', 'sg_adam_step', 'sg_lerp_multi', 'sg_images_to_float', 'sg_conv2d_reduced', 'sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask'):     # structs declared in the plugin modules
             getattr(handle, name).argtypes = [vp, vp]
             getattr(handle, name).restype = ctypes.c_int
-        for name in ('sg_styles', 'sg_styles_backward', 'sg_pack_weights'):
+        for name in ('sg_styles', 'sg_styles_backward', 'sg_pack_weights',
+           'sg_conv2d_prepared_weight_bytes', 'sg_conv2d_prepare_weights'):
             getattr(handle, name).argtypes = [vp, vp]
             getattr(handle, name).restype = ctypes.c_int
         handle.sg_conv2d_reduced.argtypes = [vp, vp, vp]
@@ -97,7 +99,9 @@ def lib():
         for name in ('sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask', 'sg_conv_up2_fir_supported'):
             getattr(handle, name).argtypes = [vp]
             getattr(handle, name).restype = ctypes.c_int
-        for name in ('sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes'):
+        handle.sg_conv2d_prepare_weights.argtypes = [vp, vp, ctypes.c_size_t, vp]
+        handle.sg_conv2d_prepare_weights.restype = ctypes.c_int
+        for name in ('sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes', 'sg_conv2d_prepared_weight_bytes'):
             getattr(handle, name).argtypes = [vp]
             getattr(handle, name).restype = ctypes.c_size_t
         handle.sg_conv2d_reduce_rows.argtypes = [vp]

@@ -28,7 +28,7 @@ class Conv2dParams(ctypes.Structure):
                 ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
                 ('reduce_x', ctypes.c_void_p), ('reduce_out', ctypes.c_void_p),
                 ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float),
-                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t), ('w_prepared', ctypes.c_void_p)]
 
 
 def _attach_workspace(p, query, like):
@@ -232,6 +232,12 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
         offset += nky * nkx * co * ci
+    prepared = None
+    if x.dtype == torch.float32 and workspace is None and memo.is_constant(w_packed) and not torch.cuda.is_current_stream_capturing():
+        # float32 weights that are constants (frozen layers; any layer until its next optimizer step): their largest
+        # magnitude and their split rows are kept with them instead of being formed again by every call
+        prepared = memo.memo(w_packed, ('float32 prepared', plan.key, co, ci), lambda: _prepare_weights(p, x))
+        p.w_prepared = prepared.data_ptr()
     if workspace is not None:
         if workspace.dtype != torch.uint8 or workspace.device != x.device or not workspace.is_contiguous():
             raise RuntimeError('workspace must be a dense uint8 tensor on the device of x')
@@ -259,6 +265,16 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
     if reduce_x is not None:
         return y, (partial.sum(dim=1) if partial.shape[1] > 1 else partial[:, 0])
     return y
+
+
+def _prepare_weights(p, like):
+    """The buffer `sg_conv2d_prepare_weights` fills for the float32 geometry p (uint8 tensor)."""
+    need = int(_lib.lib().sg_conv2d_prepared_weight_bytes(ctypes.byref(p)))
+    out = torch.empty([need], dtype=torch.uint8, device=like.device)
+    fn = _lib.lib().sg_conv2d_prepare_weights
+    _lib.launch_raw(lambda stream: fn(ctypes.byref(p), _lib.ptr(out), need, stream), like, 'sg_conv2d_prepare_weights',
+                    'split_rows_kernel', 2 * need)
+    return out
 
 
 def workspace_bytes(x, plan, co):

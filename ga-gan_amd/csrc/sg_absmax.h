@@ -18,6 +18,9 @@ namespace sg {
 int absmax_measure(hipStream_t stream, const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc,
                    const float* d, int64_t nd, const unsigned** slot);
 
+// max |a| over n floats into word 1 of the four words at dst (the other three are zeroed; dst[4..7] are written too).
+int absmax_into(hipStream_t stream, const float* a, int64_t na, unsigned* dst);
+
 // The power of two `mul` with amax * mul in [2^14, 2^15) and its inverse; both 1 when amax is zero, denormal or
 // not finite (non-finite operands poison the result either way).
 __device__ __forceinline__ void half_range_scale(float amax, float& mul, float& inv) {

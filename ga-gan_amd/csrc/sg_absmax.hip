@@ -258,4 +258,12 @@ int absmax_measure(hipStream_t stream, const float* a, int64_t na, const float* 
     return check_launch("absmax");
 }
 
+int absmax_into(hipStream_t stream, const float* a, int64_t na, unsigned* dst) {
+    FourTensors t{{nullptr, a, nullptr, nullptr}, {0, a ? na : 0, 0, 0}};
+    const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((na / 4 + 4095) / 4096, 1), 1024);
+    hipLaunchKernelGGL(absmax_reset_kernel, dim3(1), dim3(64), 0, stream, dst);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks, 4), dim3(256), 0, stream, t, dst, dst + 4);
+    return check_launch("absmax");
+}
+
 }  // namespace sg

@@ -57,6 +57,7 @@ constexpr int kPixelsHalf = 128;  // ... of the float kernel at stride 2, where 
 constexpr int kThreads = 256;
 constexpr int kPitchSplit = 128;  // bytes per LDS row of a float tensor split into 2 half planes (swizzled, no padding)
 constexpr int kSplitTaps = 3;     // taps of the weight chunk held in LDS at a time (split float path)
+constexpr size_t kPreparedHeader = 256;   // prepared weights: [largest magnitude in word 1 of 64][split rows]
 
 __device__ __forceinline__ int floor_div_i(int a, int b);
 
@@ -96,6 +97,7 @@ struct Tile {
     // float path (sg_absmax.h): largest magnitudes of x, w and in_scale (bit patterns); x and the packed weights as
     // split rows; chunks of 32 input channels
     const unsigned* amax;
+    const unsigned* wmax;   // the four words whose word 1 is the weights' largest magnitude (amax, or the prepared weights' header)
     const unsigned char* xs;
     const unsigned char* ws;
     int chunks;
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
     if constexpr (SPLIT) {
         float mul;
         half_range_scale(t.amax, 0, 2, p.in_scale != nullptr, mul, inv_x);
-        half_range_scale(t.amax, 1, 3, false, mul, inv_w);
+        half_range_scale(t.wmax, 1, 3, false, mul, inv_w);
     }
 
     // ---- split float path -------------------------------------------------------------------------------------
@@ -887,7 +889,7 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
                 t.px >= kPixels && p.ow % 8 == 0 && t.tw % 8 == 0 && aligned16(p.y) && (!p.noise || (aligned16(p.noise) && p.noise_stride_n % 4 == 0)) &&
                 (!p.reduce_out || aligned16(p.reduce_x));
     if (t.vec_epi) lds = std::max(lds, (size_t)t.px * (BM + 4) * sizeof(float));
-    t.amax = nullptr;
+    t.amax = t.wmax = nullptr;
     t.xs = t.ws = nullptr;
     t.chunks = 0;
     t.w_rows = 0;
@@ -895,11 +897,14 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
         int64_t w_elems = 0;
         for (int i = 0; i < p.num_phases; i++)
             w_elems = std::max<int64_t>(w_elems, p.phase[i].w_offset + (int64_t)p.phase[i].nky * p.phase[i].nkx * p.co * p.ci);
-        if (int rc = absmax_measure(stream, (const float*)p.x, (int64_t)p.n * p.ci * p.h * p.w_in, (const float*)p.w, w_elems,
-                                    p.in_scale, (int64_t)p.n * p.ci, nullptr, 0, &t.amax))
+        const bool prepared = p.w_prepared != nullptr;
+        SG_REQUIRE(!prepared || (reinterpret_cast<uintptr_t>(p.w_prepared) & 255u) == 0, SG_ERR_INVALID_ARGUMENT,
+                   "conv2d: w_prepared must be 256-byte aligned");
+        if (int rc = absmax_measure(stream, (const float*)p.x, (int64_t)p.n * p.ci * p.h * p.w_in, prepared ? nullptr : (const float*)p.w,
+                                    w_elems, p.in_scale, (int64_t)p.n * p.ci, nullptr, 0, &t.amax))
             return rc;
         const int64_t pixels = (int64_t)p.h * p.w_in, w_rows = w_elems / p.ci;
-        const size_t x_bytes = split_bytes((int64_t)p.n * pixels, p.ci), need = x_bytes + split_bytes(w_rows, p.ci);
+        const size_t x_bytes = split_bytes((int64_t)p.n * pixels, p.ci), need = x_bytes + (prepared ? 0 : split_bytes(w_rows, p.ci));
         unsigned char* work = (unsigned char*)p.workspace;
         if (work != nullptr) {
             SG_REQUIRE(p.workspace_bytes >= need && (reinterpret_cast<uintptr_t>(work) & 255u) == 0, SG_ERR_INVALID_ARGUMENT,
@@ -909,9 +914,15 @@ int launch(const sg_conv2d_params& p, hipStream_t stream) {
             if (work == nullptr) return (int)hipErrorOutOfMemory;
         }
         if (int rc = split_pixels(stream, (const float*)p.x, p.in_scale, p.n, p.ci, pixels, t.amax, 0, 2, work)) return rc;
-        if (int rc = split_rows(stream, (const float*)p.w, w_rows, p.ci, t.amax, 1, work + x_bytes)) return rc;
         t.xs = work;
-        t.ws = work + x_bytes;
+        if (prepared) {
+            t.wmax = (const unsigned*)p.w_prepared;
+            t.ws = (const unsigned char*)p.w_prepared + kPreparedHeader;
+        } else {
+            if (int rc = split_rows(stream, (const float*)p.w, w_rows, p.ci, t.amax, 1, work + x_bytes)) return rc;
+            t.wmax = t.amax;
+            t.ws = work + x_bytes;
+        }
         t.chunks = (int)split_chunks(p.ci);
         t.w_rows = w_rows;
     }
@@ -1161,7 +1172,33 @@ extern "C" size_t sg_conv2d_workspace_bytes(const sg_conv2d_params* p) {
     int64_t w_elems = 0;
     for (int i = 0; i < p->num_phases; i++)
         w_elems = std::max<int64_t>(w_elems, p->phase[i].w_offset + (int64_t)p->phase[i].nky * p->phase[i].nkx * p->co * p->ci);
-    return sg::split_bytes((int64_t)p->n * p->h * p->w_in, p->ci) + sg::split_bytes(w_elems / p->ci, p->ci);
+    return sg::split_bytes((int64_t)p->n * p->h * p->w_in, p->ci) + (p->w_prepared ? 0 : sg::split_bytes(w_elems / p->ci, p->ci));
+}
+
+namespace {
+int64_t packed_weight_elems(const sg_conv2d_params& p) {
+    int64_t w_elems = 0;
+    for (int i = 0; i < p.num_phases; i++)
+        w_elems = std::max<int64_t>(w_elems, p.phase[i].w_offset + (int64_t)p.phase[i].nky * p.phase[i].nkx * p.co * p.ci);
+    return w_elems;
+}
+}  // namespace
+
+extern "C" size_t sg_conv2d_prepared_weight_bytes(const sg_conv2d_params* p) {
+    if (p == nullptr || p->dtype != SG_F32 || p->ci <= 0 || p->co <= 0 || p->num_phases < 1 || p->num_phases > 4) return 0;
+    return sg::kPreparedHeader + sg::split_bytes(packed_weight_elems(*p) / p->ci, p->ci);
+}
+
+extern "C" int sg_conv2d_prepare_weights(const sg_conv2d_params* p, void* out, size_t out_bytes, sg_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t need = sg_conv2d_prepared_weight_bytes(p);
+    SG_REQUIRE(need != 0 && p->w != nullptr, SG_ERR_INVALID_ARGUMENT, "conv2d_prepare_weights: a float32 geometry with weights is needed");
+    SG_REQUIRE(out != nullptr && out_bytes >= need && (reinterpret_cast<uintptr_t>(out) & 255u) == 0, SG_ERR_INVALID_ARGUMENT,
+               "conv2d_prepare_weights: out of %zu bytes (need %zu, 256-byte aligned)", out_bytes, need);
+    const int64_t w_elems = packed_weight_elems(*p);
+    unsigned* header = (unsigned*)out;
+    if (int rc = sg::absmax_into(stream, (const float*)p->w, w_elems, header)) return rc;
+    return sg::split_rows(stream, (const float*)p->w, w_elems / p->ci, p->ci, header, 1, (unsigned char*)out + sg::kPreparedHeader);
 }
 
 extern "C" size_t sg_conv2d_wgrad_workspace_bytes(const sg_conv2d_wgrad_params* p) {

@@ -337,12 +337,25 @@ typedef struct sg_conv2d_params {
      * graph, and the buffer stays allocated until the process ends. */
     void* workspace;
     size_t workspace_bytes;
+    /* float32 calls only, may be NULL: the weights as sg_conv2d_prepare_weights left them for this geometry (their
+     * largest magnitude and their split rows).  The call then neither measures nor splits `w` again - for weights that
+     * do not change between calls (frozen layers; any layer between two optimizer steps) that is two launches and a
+     * pass over the weight tensor saved per call - and p->workspace needs room for the input's rows only. */
+    const void* w_prepared;
 } sg_conv2d_params;
 
 int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
 
-/* Bytes of p->workspace the call needs (0: none).  Depends on dtype, n, ci, h, w_in, co and the phases only. */
+/* Bytes of p->workspace the call needs (0: none).  Depends on dtype, n, ci, h, w_in, co, the phases and on whether
+ * w_prepared is given. */
 size_t sg_conv2d_workspace_bytes(const sg_conv2d_params* p);
+
+/* Prepared weights of a float32 call (see sg_conv2d_params.w_prepared): size of the buffer (0 for other dtypes), and
+ * the two launches that fill it from p->w on `stream`.  `out` is device memory, 256-byte aligned; it depends on p->w,
+ * ci, co and the phases only and may be kept as long as the weight values are.  No counterpart in the reference
+ * (cuDNN transforms filters inside its own calls). */
+size_t sg_conv2d_prepared_weight_bytes(const sg_conv2d_params* p);
+int sg_conv2d_prepare_weights(const sg_conv2d_params* p, void* out, size_t out_bytes, sg_stream_t stream);
 
 /* 1 when sg_conv2d honours p->mask_y for this geometry (decided as if mask_y were set), else 0. */
 int sg_conv2d_supports_mask(const sg_conv2d_params* p);

@@ -364,3 +364,25 @@ def test_pack_weights_kernel_matches_composition(dtype):
                 want = torch.cat(parts)
                 assert got.dtype == dtype and got.shape == want.shape
                 assert torch.equal(got, want), (co, ci, k, plan.kind, transposed)
+
+
+def test_float32_prepared_weights_give_the_same_bits():
+    """A float32 call whose packed weight is a constant keeps the weight's largest magnitude and split rows with it
+    (sg_conv2d_prepare_weights); the result equals the call that measures and splits the weight itself, bit for bit,
+    for plain, strided and transposed geometries, and a second call serves the kept buffer."""
+    from ga_gan_amd import conv2d_plugin as cp
+    from ga_gan_amd.torch_utils import memo
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 96, 20, 24, generator=g).to(DEV)
+    s = (torch.rand(4, 96, generator=g) + 0.5).to(DEV)
+    for plan, co in ((cp.plan_conv(3, 3, padding=1), 80), (cp.plan_conv(3, 3, stride=2, padding=0), 64),
+                     (cp.plan_conv_transpose(3, 3, stride=2, padding=0), 48), (cp.plan_conv(1, 1), 3)):
+        shape = [96, co, 3, 3] if plan.kind == 'conv_transpose' else [co, 96, plan.kh, plan.kw]
+        w = (torch.randn(shape, generator=g) * 0.05).to(DEV)
+        packed = plan._pack(w, plan.kind == 'conv_transpose')
+        plain = cp.conv2d(x, packed, plan, co, in_scale=s)
+        kept = memo.constant(packed.clone())
+        first = cp.conv2d(x, kept, plan, co, in_scale=s)
+        assert any(k[0] == 'float32 prepared' for k in kept._sg_memo), plan.kind
+        again = cp.conv2d(x, kept, plan, co, in_scale=s)
+        assert torch.equal(first, plain) and torch.equal(again, plain), plan.kind
