@@ -19,7 +19,7 @@ SYMBOLS = ('sg_version', 'sg_last_error', 'sg_init', 'sg_upfirdn2d_out_size', 's
            'sg_conv2d_workspace_bytes', 'sg_conv2d_wgrad_workspace_bytes', 'sg_conv_up2_fir', 'sg_conv_up2_fir_supported',
            'sg_upfirdn2d_add', 'sg_upfirdn2d_add_supported', 'sg_upfirdn2d_kernel', 'sg_planes_segments', 'sg_scale_planes', 'sg_dot_planes',
            'sg_styles', 'sg_styles_backward', 'sg_pack_weights',
-           'sg_conv2d_prepared_weight_bytes', 'sg_conv2d_prepare_weights')
+           'sg_conv2d_prepared_weight_bytes', 'sg_conv2d_prepare_weights', 'sg_conv2d_supports_addend')
 
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -89,14 +89,14 @@ def lib():
             getattr(handle, name).argtypes = [vp, vp]
             getattr(handle, name).restype = ctypes.c_int
         for name in ('sg_styles', 'sg_styles_backward', 'sg_pack_weights',
-           'sg_conv2d_prepared_weight_bytes', 'sg_conv2d_prepare_weights'):
+           'sg_conv2d_prepared_weight_bytes', 'sg_conv2d_prepare_weights', 'sg_conv2d_supports_addend'):
             getattr(handle, name).argtypes = [vp, vp]
             getattr(handle, name).restype = ctypes.c_int
         handle.sg_conv2d_reduced.argtypes = [vp, vp, vp]
         handle.sg_conv2d_reduced.restype = ctypes.c_int
         handle.sg_conv_up2_fir.argtypes = [vp, vp]
         handle.sg_conv_up2_fir.restype = ctypes.c_int
-        for name in ('sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask', 'sg_conv_up2_fir_supported'):
+        for name in ('sg_conv2d_supports_mask', 'sg_conv2d_wgrad_supports_mask', 'sg_conv_up2_fir_supported', 'sg_conv2d_supports_addend'):
             getattr(handle, name).argtypes = [vp]
             getattr(handle, name).restype = ctypes.c_int
         handle.sg_conv2d_prepare_weights.argtypes = [vp, vp, ctypes.c_size_t, vp]

@@ -28,7 +28,8 @@ class Conv2dParams(ctypes.Structure):
                 ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
                 ('reduce_x', ctypes.c_void_p), ('reduce_out', ctypes.c_void_p),
                 ('mask_y', ctypes.c_void_p), ('mask_alpha', ctypes.c_float), ('mask_clamp', ctypes.c_float),
-                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t), ('w_prepared', ctypes.c_void_p)]
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t), ('w_prepared', ctypes.c_void_p),
+                ('addend', ctypes.c_void_p)]
 
 
 def _attach_workspace(p, query, like):
@@ -167,7 +168,7 @@ REDUCED_MAX_PARTIALS = 1 << 20   # SG_CONV2D_REDUCED_MAX_PARTIALS of include/sg_
 
 def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, noise=None, noise_gain=None,
            act='linear', alpha=0.2, gain=1.0, clamp=-1.0, out_hw=None, reduce_x=None, out=None, reduce_sum=None,
-           mask_y=None, mask_alpha=1.0, mask_clamp=-1.0, workspace=None):
+           mask_y=None, mask_alpha=1.0, mask_clamp=-1.0, workspace=None, addend=None):
     """Run `plan` on x [n, ci, h, w] (dense NCHW) with packed weights; returns y [n, co, oh, ow].
     `out_hw` overrides the plan's natural output size (pixels whose taps all fall outside x are zero).
     With `reduce_x` (y's shape and dtype) the call returns (y, r), r[n, co] = sum over pixels of
@@ -221,13 +222,15 @@ def conv2d(x, w_packed, plan, co, in_scale=None, out_scale=None, bias=None, nois
         raise RuntimeError('reduce_x must be dense and match the output')
     if mask_y is not None and (mask_y.shape != x.shape or mask_y.dtype != x.dtype or not mask_y.is_contiguous()):
         raise RuntimeError('mask_y must be dense and match x')
+    if addend is not None and (addend.shape != y.shape or addend.dtype != x.dtype or not addend.is_contiguous()):
+        raise RuntimeError('addend must be dense and match the output')
     p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(w_packed), y=_lib.ptr(y), in_scale=_lib.ptr(in_scale),
                      out_scale=_lib.ptr(out_scale), bias=_lib.ptr(bias), noise=_lib.ptr(noise),
                      noise_gain=_lib.ptr(noise_gain), noise_stride_n=noise_stride, dtype=_lib.dtype_code(x),
                      n=n, ci=ci, h=h, w_in=w, co=co, oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step,
                      num_phases=len(plan.phases), act=ACT_INDEX[act], alpha=alpha, gain=gain, clamp=clamp,
                      reduce_x=_lib.ptr(reduce_x), reduce_out=None, mask_y=_lib.ptr(mask_y), mask_alpha=mask_alpha,
-                     mask_clamp=mask_clamp)
+                     mask_clamp=mask_clamp, addend=_lib.ptr(addend))
     offset = 0
     for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
@@ -306,6 +309,22 @@ def supports_mask(x, plan, co, out_hw=None, reduce=False):
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
         offset += nky * nkx * co * ci
     return bool(_lib.lib().sg_conv2d_supports_mask(ctypes.byref(p)))
+
+
+def supports_addend(x, plan, co, out_hw=None, epilogue_free=True):
+    """True when `conv2d(x, ..., addend=...)` has a kernel for this geometry (no modulation, no noise)."""
+    if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in _DTYPE_NAME:
+        return False
+    n, ci, h, w = x.shape
+    oh, ow = plan.out_size(h, w) if out_hw is None else out_hw
+    p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(x), y=_lib.ptr(x), addend=_lib.ptr(x), dtype=_lib.dtype_code(x), n=n, ci=ci, h=h,
+                     w_in=w, co=co, oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step, num_phases=len(plan.phases),
+                     act=1, gain=1.0, clamp=-1.0, mask_clamp=-1.0)
+    offset = 0
+    for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
+        p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)
+        offset += nky * nkx * co * ci
+    return bool(_lib.lib().sg_conv2d_supports_addend(ctypes.byref(p)))
 
 
 def kernel_name(x, plan, co, out_hw=None):

@@ -1128,6 +1128,10 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
                SG_ERR_INVALID_ARGUMENT, "conv2d: tensor is too large");
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->w && p->y, SG_ERR_NULL_POINTER, "conv2d: x, w and y must not be NULL");
+    if (p->addend != nullptr) {
+        SG_REQUIRE(pointwise_eligible(*p), SG_ERR_UNSUPPORTED, "conv2d: no kernel adds a tensor to the result for this geometry");
+        return pointwise_launch(*p, (hipStream_t)stream);
+    }
     if (conv1x1_few_eligible(*p)) return conv1x1_few_launch(*p, (hipStream_t)stream);
     if (band3x3_eligible(*p)) return band3x3_launch(*p, (hipStream_t)stream);
     SG_REQUIRE(p->mask_y == nullptr, SG_ERR_UNSUPPORTED, "conv2d: no kernel applies an input mask for this geometry");
@@ -1214,6 +1218,11 @@ extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
     int taps = 0;
     const sg::Tile t = sg::make_tile(*p, &taps);
     return (t.imgs == 1) ? t.tiles_a * t.tiles_b * p->num_phases : 1;
+}
+
+extern "C" int sg_conv2d_supports_addend(const sg_conv2d_params* p) {
+    if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return 0;
+    return sg::pointwise_eligible(*p) ? 1 : 0;
 }
 
 extern "C" int sg_conv2d_supports_mask(const sg_conv2d_params* p) {

@@ -37,6 +37,7 @@ constexpr int kWRow = 64;               // bytes per staged weight row
 
 struct PwArgs {
     const void* x; const void* w; void* y; const void* bias;
+    const void* addend;   // added to the result after the epilogue, or null
     int n, ci, co;
     int64_t hw;           // pixels per plane, a multiple of 8
     int tiles_img;        // pixel tiles per image
@@ -66,6 +67,13 @@ __device__ __forceinline__ uint2 read_tr(const unsigned char* p) {
 template <class T> __device__ __forceinline__ unsigned pack2(float a, float b) {
     return (unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(a)) |
            ((unsigned)__builtin_bit_cast(unsigned short, Elem<T>::store(b)) << 16);
+}
+
+template <class T> __device__ __forceinline__ float unpack_lo(unsigned v) {
+    return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(v & 0xffffu)));
+}
+template <class T> __device__ __forceinline__ float unpack_hi(unsigned v) {
+    return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(v >> 16)));
 }
 
 template <class T, int NTL>   // NTL: 16-channel output tiles per workgroup
@@ -168,6 +176,7 @@ __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(P
 
     // ---- epilogue: rows 4 lgrp .. 4 lgrp + 3 of tile t are 4 consecutive pixels, the column is the channel ------------
     T* __restrict__ y = (T*)a.y;
+    const T* __restrict__ add = (const T*)a.addend;
     const int64_t px0 = p0 + wave * 64 + lgrp * 4;
 #pragma unroll
     for (int j = 0; j < NTL; j++) {
@@ -185,6 +194,13 @@ __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(P
                 float z = acc[t][j][e] + bs;
                 z = (z > 0.f) ? z : z * a.slope;
                 r[e] = fminf(fmaxf(z * a.gain, -a.hi), a.hi);
+            }
+            if (add) {     // the other branch of a residual block: both summands are rounded values of the tensor's type, the sum is rounded once
+                const uint2 v = *reinterpret_cast<const uint2*>(add + (dst - y) + px);
+                r[0] = Elem<T>::load(Elem<T>::store(r[0])) + unpack_lo<T>(v.x);
+                r[1] = Elem<T>::load(Elem<T>::store(r[1])) + unpack_hi<T>(v.x);
+                r[2] = Elem<T>::load(Elem<T>::store(r[2])) + unpack_lo<T>(v.y);
+                r[3] = Elem<T>::load(Elem<T>::store(r[3])) + unpack_hi<T>(v.y);
             }
             *reinterpret_cast<uint2*>(dst + px) = make_uint2(pack2<T>(r[0], r[1]), pack2<T>(r[2], r[3]));
         }
@@ -204,7 +220,7 @@ int launch_tiles(const PwArgs& a, hipStream_t stream) {
 template <class T>
 int launch_pointwise(const sg_conv2d_params& p, hipStream_t stream) {
     PwArgs a;
-    a.x = p.x; a.w = p.w; a.y = p.y; a.bias = p.bias;
+    a.x = p.x; a.w = p.w; a.y = p.y; a.bias = p.bias; a.addend = p.addend;
     a.n = p.n; a.ci = p.ci; a.co = p.co;
     a.hw = (int64_t)p.h * p.w_in;
     a.tiles_img = (int)((a.hw + TP - 1) / TP);
@@ -230,7 +246,7 @@ bool pointwise_eligible(const sg_conv2d_params& p) {
     if (p.ci < 32 || p.ci % KCH != 0 || p.co < 16) return false;
     const int64_t hw = (int64_t)p.h * p.w_in;
     if (hw % 8 != 0 || hw < 1024) return false;
-    return aligned16(p.x) && aligned16(p.y) && aligned16(p.w);
+    return aligned16(p.x) && aligned16(p.y) && aligned16(p.w) && aligned16(p.addend);
 }
 
 int pointwise_launch(const sg_conv2d_params& p, hipStream_t stream) {

@@ -128,7 +128,7 @@ class _FusedConv(torch.autograd.Function):
     mode 'up2' : y = epilogue(blur(conv_transpose(x * styles, w; stride 2), f, blur_pad, gain 4))."""
 
     @staticmethod
-    def forward(ctx, x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg):
+    def forward(ctx, x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg, addend=None):
         mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
         x = x.contiguous()
         co = w.shape[0]
@@ -136,8 +136,9 @@ class _FusedConv(torch.autograd.Function):
                   gain=gain, clamp=clamp)
         if mode == 'same':
             plan = _conv.plan_conv(k, k, stride=stride, padding=padding)
-            y = _conv.conv2d(x, plan.pack(w), plan, co, in_scale=styles, out_scale=dcoefs, out_hw=out_hw, **ep)
+            y = _conv.conv2d(x, plan.pack(w), plan, co, in_scale=styles, out_scale=dcoefs, out_hw=out_hw, addend=addend, **ep)
         else:
+            assert addend is None
             plan = _conv.plan_conv_transpose(k, k, stride=2, padding=0)
             th, tw = plan.out_size(x.shape[2], x.shape[3])
             ctx.t_shape = (x.shape[0], co, th, tw + extra)
@@ -150,6 +151,7 @@ class _FusedConv(torch.autograd.Function):
         # the output is only needed where the backward reads it: activation slope, clamp mask, demodulation
         # gradient; a linear, unclamped layer (the residual skips) may then be updated in place by its caller
         keep_y = act != 'linear' or clamp >= 0 or dcoefs is not None
+        assert addend is None or not keep_y    # (the sum would hide the layer's own output from its backward)
         ctx.save_for_backward(x, w, styles, dcoefs, noise, noise_strength, bias, f, y if keep_y else None)
         ctx.w_memo = getattr(w, '_sg_memo', None)
         ctx.cfg = cfg
@@ -162,7 +164,8 @@ class _FusedConv(torch.autograd.Function):
             w._sg_memo = ctx.w_memo
         cfg = ctx.cfg
         mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
-        need = ctx.needs_input_grad   # x, w, styles, dcoefs, noise, noise_strength, bias
+        need = ctx.needs_input_grad   # x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg, addend
+        d_addend = dy if len(need) > 9 and need[9] else None
 
         if torch.is_grad_enabled():   # a higher-order graph is wanted: differentiate the composite instead
             with torch.enable_grad():
@@ -174,9 +177,10 @@ class _FusedConv(torch.autograd.Function):
                 out = _composite(ins[0], ins[1], ins[2], ins[3], noise, ins[5], ins[6], f, cfg)
                 wanted = [i for i in range(7) if need[i] and ins[i] is not None]
                 grads = torch.autograd.grad(out, [ins[i] for i in wanted], dy, create_graph=True, allow_unused=True)
-            result = [None] * 9
+            result = [None] * 10
             for i, g in zip(wanted, grads):
                 result[i] = g
+            result[9] = d_addend
             return tuple(result)
 
         ep = dict(scale=dcoefs, noise=noise, noise_gain=noise_strength if noise is not None else None, bias=bias, act=act,
@@ -213,7 +217,7 @@ class _FusedConv(torch.autograd.Function):
                           * gain).to(w.dtype)
                 return (dx if need[0] else None, dw, dstyles, ddcoefs, None,
                         dng.reshape(noise_strength.shape) if dng is not None else None,
-                        dbias.to(bias.dtype) if dbias is not None else None, None, None)
+                        dbias.to(bias.dtype) if dbias is not None else None, None, None, d_addend)
         dz, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y if y is not None else dy, **want, **ep)
         if mode == 'same':
             if want_dx:
@@ -240,7 +244,7 @@ class _FusedConv(torch.autograd.Function):
         if not need[0]:
             dx = None
         return (dx, dw, dstyles, ddcoefs, None, dng.reshape(noise_strength.shape) if dng is not None else None,
-                dbias.to(bias.dtype) if dbias is not None else None, None, None)
+                dbias.to(bias.dtype) if dbias is not None else None, None, None, d_addend)
 
 
 def _down_padding(f, k, padding, down=2):
@@ -258,12 +262,14 @@ def branch_down(x, f, padding=0):
 
 
 def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=None, dcoefs=None, noise=None,
-               noise_strength=None, bias=None, act='linear', alpha=None, gain=None, clamp=None, prefiltered=False):
+               noise_strength=None, bias=None, act='linear', alpha=None, gain=None, clamp=None, prefiltered=False, addend=None):
     """clamp(act(conv2d_resample(x * styles, w, f, up, down, padding) * dcoefs + noise * noise_strength + bias) * gain).
 
     x [N, I, H, W]; w [O, I, k, k] in x's dtype; styles [N, I] / dcoefs [N, O] float32 or None; noise a
     float32 plane [H', W'] or [N, 1, H', W'] (unit noise) with its scalar strength; bias [O] in x's dtype.
-    Call `supported()` first.
+    Call `supported()` first.  `addend` (the output's shape and dtype) is added to the result: by the layer's own
+    kernel while it stores where one does that (16-bit 1x1 layers without modulation, activation or clamp - the skip
+    of a residual block), else in place afterwards.
     """
     spec = bias_act.activation_funcs[act]
     alpha = float(spec.def_alpha if alpha is None else alpha)
@@ -313,5 +319,12 @@ def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=N
         extra = _align_extra((x.shape[3] - 1) * up + k)
         cfg = ('up2', k, 2, 0, None, act, alpha, gain, clamp, (px0, px1 - extra, py0, py1), extra)
     if _twice and torch.is_grad_enabled():
-        return _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
-    return _FusedConv.apply(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
+        y = _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
+        return y if addend is None else y.add_(addend)
+    if addend is not None:
+        fused = (cfg[0] == 'same' and k == 1 and styles is None and dcoefs is None and noise is None and act == 'linear'
+                 and clamp < 0 and addend.is_contiguous()
+                 and _conv.supports_addend(x.contiguous(), _conv.plan_conv(1, 1), int(w.shape[0]), out_hw=cfg[4]))
+        if not fused:
+            return _FusedConv.apply(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg).add_(addend)
+    return _FusedConv.apply(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg, addend)

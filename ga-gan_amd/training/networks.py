@@ -496,9 +496,13 @@ class Conv2dLayer(torch.nn.Module):
             else:
                 self.bias = None
 
-    def forward(self, x, gain=1, also_input=False):
+    def forward(self, x, gain=1, also_input=False, residual=None):
         """`also_input=True` returns (x, y) for a caller that feeds x to a second layer as well: it must use the returned
-        x there (a 16-bit down-sampling 1x1 layer then receives both gradients of x in its filter's backward kernel)."""
+        x there (a 16-bit down-sampling 1x1 layer then receives both gradients of x in its filter's backward kernel).
+        `residual`: a callable; the result is layer(x) + residual(x) - the two branches of a residual block, with the
+        other branch evaluated first so that this layer's kernel can add it while it stores its own result."""
+        if residual is not None:
+            return self._with_residual(x, gain, residual)
         w = _prepared(self, self.weight, self.weight_gain, x.dtype, 'w')
         b = _prepared(self, self.bias, 1, x.dtype, 'b') if self.bias is not None else None
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
@@ -517,6 +521,25 @@ class Conv2dLayer(torch.nn.Module):
                                             padding=self.padding, flip_weight=(self.up == 1))
         y = bias_act.bias_act(y, b, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
         return (x, y) if also_input else y
+
+
+def _conv2d_layer_with_residual(self, x, gain, residual):
+    w = _prepared(self, self.weight, self.weight_gain, x.dtype, 'w')
+    b = _prepared(self, self.bias, 1, x.dtype, 'b') if self.bias is not None else None
+    act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+    if not (FUSE_LAYERS and self.activation in ('linear', 'lrelu') and fused_layer.supported(x, w, self.up, self.down)):
+        x, y = self.forward(x, gain=gain, also_input=True)
+        return y.add_(residual(x))
+    kwargs = dict(f=self.resample_filter, up=self.up, down=self.down, padding=self.padding, flip_weight=(self.up == 1), bias=b,
+                  act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
+    if self.down == 2 and w.shape[2] == 1 and x.dtype != torch.float32 and x.requires_grad and x.is_contiguous() \
+            and self.resample_filter.ndim == 2:
+        x, xd = fused_layer.branch_down(x, self.resample_filter, self.padding)
+        return fused_layer.conv_layer(xd, w, prefiltered=True, addend=residual(x), **kwargs)
+    return fused_layer.conv_layer(x, w, addend=residual(x), **kwargs)
+
+
+Conv2dLayer._with_residual = _conv2d_layer_with_residual
 
 
 class MappingNetwork(torch.nn.Module):
@@ -846,8 +869,7 @@ class DiscriminatorBlock(torch.nn.Module):
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
             half = np.sqrt(0.5)                       # both branches scaled so that their sum keeps the variance
-            x, shortcut = self.skip(x, gain=half, also_input=True)
-            x = shortcut.add_(self.conv1(self.conv0(x), gain=half))
+            x = self.skip(x, gain=half, residual=lambda t: self.conv1(self.conv0(t), gain=half))
         else:
             x = self.conv1(self.conv0(x))
         assert x.dtype == dtype

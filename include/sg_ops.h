@@ -342,6 +342,11 @@ typedef struct sg_conv2d_params {
      * do not change between calls (frozen layers; any layer between two optimizer steps) that is two launches and a
      * pass over the weight tensor saved per call - and p->workspace needs room for the input's rows only. */
     const void* w_prepared;
+    /* may be NULL: a tensor of y's shape and dtype that is added to the result after the epilogue, y = epilogue(...) +
+     * addend - the sum of a residual block (training/networks.py:1268-1271 `x = y.add_(x)`) formed while the skip
+     * branch is stored instead of in a pass of its own.  Only where sg_conv2d_supports_addend(p) returns 1 (16-bit 1x1
+     * layers with at least 32 input and 16 output channels and no modulation); other calls return SG_ERR_UNSUPPORTED. */
+    const void* addend;
 } sg_conv2d_params;
 
 int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream);
@@ -354,6 +359,7 @@ size_t sg_conv2d_workspace_bytes(const sg_conv2d_params* p);
  * the two launches that fill it from p->w on `stream`.  `out` is device memory, 256-byte aligned; it depends on p->w,
  * ci, co and the phases only and may be kept as long as the weight values are.  No counterpart in the reference
  * (cuDNN transforms filters inside its own calls). */
+int sg_conv2d_supports_addend(const sg_conv2d_params* p);
 size_t sg_conv2d_prepared_weight_bytes(const sg_conv2d_params* p);
 int sg_conv2d_prepare_weights(const sg_conv2d_params* p, void* out, size_t out_bytes, sg_stream_t stream);
 

@@ -71,7 +71,8 @@ def test_branch_gradient_equals_separate_sum(dtype):
 
 
 def test_discriminator_block_with_and_without_branch():
-    """A residual block in bfloat16: output and input gradient with the branch op equal those of the plain form."""
+    """A residual block in bfloat16: output and input gradient with the branch op and the sum formed by the skip
+    layer's kernel equal those of the plain form (filter, layers, then the sum in a pass of its own)."""
     from ga_gan_amd.training import networks
     torch.manual_seed(0)
     block = networks.DiscriminatorBlock(32, 32, 64, resolution=128, first_layer_idx=0, use_fp16=True, conv_clamp=256,
@@ -82,8 +83,10 @@ def test_discriminator_block_with_and_without_branch():
     for use_branch in (True, False):
         saved = networks.Conv2dLayer.forward
         if not use_branch:
-            def plain(self, x, gain=1, also_input=False, _f=saved):
+            def plain(self, x, gain=1, also_input=False, residual=None, _f=saved):
                 y = _f(self, x, gain=gain)
+                if residual is not None:      # (the sum in a pass of its own, after both branches)
+                    return y.add_(residual(x))
                 return (x, y) if also_input else y
             networks.Conv2dLayer.forward = plain
         try:
