@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 namespace sg {
 namespace {
@@ -179,24 +180,40 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
     uint4 va[STEPS], vb[STEPS], vw[9];
     float s0 = 1.f, s1 = 1.f;
 
-    auto fetch = [&](int c0) {
+    // The loads of a chunk: 2 STEPS input packets, the two modulation scales, 9 weight packets per lane.  The texture
+    // path of a CU takes 16 cycles per 16-byte load instruction of a wave, 8 waves x 15 loads = 1,900 cycles per chunk:
+    // issued as one batch in front of the multiply phase, the loads queue there and the waves start multiplying one
+    // after the other as their batches get through (cycle stamps: the last wave of a SIMD entered its multiply
+    // phase 3,000 cycles after the barrier, its SIMD partner waited 2,600 at the next one).  So only the first chunk is
+    // fetched as a batch; every other chunk's loads are dealt over the nine taps of the multiply phase before it
+    // (fetch_part), one or two instructions beside 16 matrix instructions.
+    rsrc_t d_x = make_rsrc(xs, 0u), d_s = make_rsrc(xs, 0u), d_w = make_rsrc(xs, 0u);
+    unsigned wv = kOutside;
+    auto fetch_begin = [&](int c0) {
         const int left = min(KCH, g.ci - c0);                       // channels of this chunk
-        const rsrc_t rx = make_rsrc(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
+        d_x = make_rsrc(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
+        if constexpr (MOD) d_s = make_rsrc(g.in_scale + (size_t)n * g.ci + c0, (unsigned)left * 4u);
+        d_w = make_rsrc(w + c0, 9u * w_tap);
+        wv = (w_c < left) ? w_voff : kOutside;       // the lane's slot of 8 channels lies in the chunk or not
+    };
+    auto fetch_part = [&](int t) {                   // t = 0 .. 8
 #pragma unroll
-        for (int q = 0; q < STEPS; q++) {
-            va[q] = load16(rx, voff[q], 0);
-            vb[q] = load16(rx, voff[q], plane_bytes);               // channel 2 cg + 1 (ci is a multiple of 8)
+        for (int l = 0; l < 2 * STEPS; l++) {        // load l = packet of channel 2 cg + (l & 1) of item l >> 1
+            if ((l * 9) / (2 * STEPS) != t) continue;
+            if (l & 1) vb[l >> 1] = load16(d_x, voff[l >> 1], plane_bytes);      // (ci is a multiple of 8)
+            else va[l >> 1] = load16(d_x, voff[l >> 1], 0);
         }
         if constexpr (MOD) {
-            const rsrc_t rs = make_rsrc(g.in_scale + (size_t)n * g.ci + c0, (unsigned)left * 4u);
             // (two dword loads: hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to a single dword load)
-            s0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 0, 0));   // zero beyond the last channel
-            s1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 4, 0));
+            if (t == 4) s0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s, cg * 8, 0, 0));   // zero beyond the last channel
+            if (t == 5) s1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s, cg * 8, 4, 0));
         }
-        const rsrc_t rw = make_rsrc(w + c0, 9u * w_tap);
-        const unsigned wv = (w_c < left) ? w_voff : kOutside;       // the lane's slot of 8 channels lies in the chunk or not
+        vw[t] = load16(d_w, wv, (unsigned)t * w_tap);
+    };
+    auto fetch = [&](int c0) {
+        fetch_begin(c0);
 #pragma unroll
-        for (int q = 0; q < 9; q++) vw[q] = load16(rw, wv, (unsigned)q * w_tap);
+        for (int t = 0; t < 9; t++) fetch_part(t);
     };
 
     auto commit = [&]() {
@@ -286,12 +303,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
             b[j] = *reinterpret_cast<const uint4*>(s_in + row * kRow + (((lgrp ^ (row >> 1)) & 3) << 4));
         }
     };
-    auto multiply = [&]() {
+    auto multiply = [&](auto with_fetch) {
         uint4 fa[2][4], fb[2][4];
         read_tap(0, fa[0], fb[0]);
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             if (tap + 1 < 9) read_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+            if constexpr (decltype(with_fetch)::value) fetch_part(tap);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -306,14 +324,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
         __syncthreads();   // everyone is done reading the previous chunk
         commit();
         __syncthreads();
-        fetch(c0 + KCH);   // in flight during the multiply phase
-        multiply();
+        fetch_begin(c0 + KCH);
+        multiply(std::true_type{});      // (the next chunk's loads are issued between its taps)
     }
     __syncthreads();
     commit();
     __syncthreads();
     fetch_epilogue();      // the last chunk's multiply phase covers the epilogue's loads instead
-    multiply();
+    multiply(std::false_type{});
 
     // ---- epilogue: straight-line arithmetic (scale 1, noise 0, bias 0, slope 1, clamp +-inf are no-ops) -------
     const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
