@@ -151,44 +151,59 @@ __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p)
     uint4 xa[X_STEPS], xb[X_STEPS], ga[G_STEPS], gb[G_STEPS];
     float xs0 = 1.f, xs1 = 1.f, gs0 = 1.f, gs1 = 1.f;
 
-    auto fetch = [&](int tile) {
+    // The loads of a tile: X_STEPS + G_STEPS pairs of packets per lane (12 at unit stride, 26 at stride 2).  The texture
+    // path of a CU takes 16 cycles per 16-byte load instruction of a wave, so a tile's loads keep it busy for 1,500 -
+    // 1,700 cycles: issued as one batch they queue there while nothing multiplies.  Only the first tile is fetched as
+    // a batch; every other tile's loads are dealt over the k-steps of the multiply phase before it (fetch_part).
+    constexpr int PARTS = X_STEPS + G_STEPS;
+    constexpr int K_STEPS = TH / (WAVES / 4);                      // k-steps of a wave per tile (fewer on narrow blocks)
+    constexpr int PER_STEP = (PARTS + K_STEPS - 1) / K_STEPS;      // parts issued beside one k-step
+    rsrc_t d_x = make_rsrc(x, 0u), d_g = make_rsrc(x, 0u);
+    int f_iy = 0, f_px = 0, f_a0 = 0, f_b0 = 0, f_n = 0;
+    auto fetch_begin = [&](int tile) {
         const int tb = tile % p.tiles_b; tile /= p.tiles_b;
         const int ta = tile % p.tiles_a;
-        const int n = tile / p.tiles_a;
-        const int a0 = ta * TH, b0 = tb * TW;
-        {
-            const rsrc_t rx = make_rsrc(x + (size_t)(n * p.cx + cx0) * x_plane, (unsigned)x_left * x_plane_bytes);
-            const int iy_first = a0 * STEP + p.dy0, px_first = b0 * STEP + p.px_shift;
-#pragma unroll
-            for (int s = 0; s < X_STEPS; s++) {
-                const int iy = iy_first + x_ry[s], px0 = px_first + x_px[s];
-                const bool ok = iy >= 0 && iy < p.h && px0 >= 0 && px0 < p.wid;
-                const unsigned voff = ok ? (unsigned)(2 * cp * x_plane + iy * p.wid + px0) * 2u : kOutside;
-                xa[s] = load16(rx, voff, 0);
-                xb[s] = load16(rx, voff, x_plane_bytes);              // channel 2 cp + 1 (channel counts are multiples of 8)
-            }
+        f_n = tile / p.tiles_a;
+        f_a0 = ta * TH; f_b0 = tb * TW;
+        d_x = make_rsrc(x + (size_t)(f_n * p.cx + cx0) * x_plane, (unsigned)x_left * x_plane_bytes);
+        d_g = make_rsrc(g + (size_t)(f_n * p.cg + cg0) * g_plane, (unsigned)g_left * g_plane_bytes);
+        f_iy = f_a0 * STEP + p.dy0; f_px = f_b0 * STEP + p.px_shift;
+    };
+    auto fetch_part = [&](int part) {                              // part: a compile-time constant at every call
+        if (part < X_STEPS) {
+            const int s = part < X_STEPS ? part : 0;
+            const int iy = f_iy + x_ry[s], px0 = f_px + x_px[s];
+            const bool ok = iy >= 0 && iy < p.h && px0 >= 0 && px0 < p.wid;
+            const unsigned voff = ok ? (unsigned)(2 * cp * x_plane + iy * p.wid + px0) * 2u : kOutside;
+            xa[s] = load16(d_x, voff, 0);
+            xb[s] = load16(d_x, voff, x_plane_bytes);              // channel 2 cp + 1 (channel counts are multiples of 8)
             if constexpr (XS) {
-                const rsrc_t rs = make_rsrc(p.x_scale + (size_t)n * p.cx + cx0, (unsigned)x_left * 4u);
-                xs0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 0, 0));
-                xs1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 4, 0));
+                if (part == 0) {
+                    const rsrc_t rs = make_rsrc(p.x_scale + (size_t)f_n * p.cx + cx0, (unsigned)x_left * 4u);
+                    xs0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 0, 0));
+                    xs1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 4, 0));
+                }
             }
-        }
-        {
-            const rsrc_t rg = make_rsrc(g + (size_t)(n * p.cg + cg0) * g_plane, (unsigned)g_left * g_plane_bytes);
-#pragma unroll
-            for (int s = 0; s < G_STEPS; s++) {
-                const int a = a0 + g_ra[s], b = b0 + g_pb[s];
-                const bool ok = a < p.gh && b < p.gw;
-                const unsigned voff = ok ? (unsigned)(2 * cp * g_plane + a * p.gw + b) * 2u : kOutside;
-                ga[s] = load16(rg, voff, 0);
-                gb[s] = load16(rg, voff, g_plane_bytes);
-            }
+        } else {
+            const int s = part >= X_STEPS ? part - X_STEPS : 0;
+            const int a = f_a0 + g_ra[s], b = f_b0 + g_pb[s];
+            const bool ok = a < p.gh && b < p.gw;
+            const unsigned voff = ok ? (unsigned)(2 * cp * g_plane + a * p.gw + b) * 2u : kOutside;
+            ga[s] = load16(d_g, voff, 0);
+            gb[s] = load16(d_g, voff, g_plane_bytes);
             if constexpr (GS) {
-                const rsrc_t rs = make_rsrc(p.g_scale + (size_t)n * p.cg + cg0, (unsigned)g_left * 4u);
-                gs0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 0, 0));
-                gs1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 4, 0));
+                if (part == X_STEPS) {
+                    const rsrc_t rs = make_rsrc(p.g_scale + (size_t)f_n * p.cg + cg0, (unsigned)g_left * 4u);
+                    gs0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 0, 0));
+                    gs1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cp * 8, 4, 0));
+                }
             }
         }
+    };
+    auto fetch = [&](int tile) {
+        fetch_begin(tile);
+#pragma unroll
+        for (int part = 0; part < PARTS; part++) fetch_part(part);
     };
 
     // pixels 0 .. 7 of one channel pair -> rows dst + j * pitch (the image rows hold whole packets: no column test)
@@ -261,9 +276,18 @@ __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p)
         __syncthreads();   // everyone is done reading the previous tile
         commit();
         __syncthreads();
-        if (tile + (int)gridDim.x < p.tiles_total) fetch(tile + gridDim.x);   // in flight during the multiply phase
-#pragma unroll 2
-        for (int ks = ks0; ks < TH; ks += ks_stride) {
+        const bool more = tile + (int)gridDim.x < p.tiles_total;
+        if (more) fetch_begin(tile + gridDim.x);
+        int done = 0;                                   // k-steps this wave has run (uniform)
+#pragma unroll
+        for (int i = 0; i < K_STEPS; i++) {
+            const int ks = ks0 + i * ks_stride;
+            if (ks >= TH) break;
+            done = i + 1;
+            if (more) {                                 // the next tile's loads of this k-step: in flight during the multiplies
+#pragma unroll
+                for (int part = i * PER_STEP; part < (i + 1) * PER_STEP && part < PARTS; part++) fetch_part(part);
+            }
             uint4 a[2];
 #pragma unroll
             for (int m = 0; m < 2; m++) {
@@ -281,6 +305,11 @@ __global__ void __launch_bounds__(64 * WAVES, 1) wgrad3x3_kernel(Wgrad3x3Args p)
                     for (int m = 0; m < 2; m++) Mma16<T>::run(a[m], b, acc[tp][m][n]);
                 }
             }
+        }
+        if (more && done < K_STEPS) {                   // (a wave that shares its sub-block's k-steps ran fewer of them)
+#pragma unroll
+            for (int part = 0; part < PARTS; part++)
+                if (part >= done * PER_STEP) fetch_part(part);
         }
     }
 
