@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
+#include <utility>
 
 namespace sg {
 namespace {
@@ -48,6 +49,7 @@ template <int STEP> struct Geo {
     static constexpr int kInBytes = LH * LWP * kRow;               // 30720 / 78336
     static constexpr int ITEMS = LH * NV;                          // (row, packet) items per channel pair
     static constexpr int STEPS = (ITEMS + 15) / 16;                // items per lane: 4 / 10
+    static constexpr int kInPadded = STEPS * 16 * 8 * kRow;        // the image with room for all 16 STEPS item slots: 32768 / 81920
     static constexpr int BLOCKS_PER_CU = (kInBytes + kWBytes) * 2 <= 160 * 1024 ? 2 : 1;
 };
 
@@ -104,9 +106,27 @@ constexpr unsigned kOutside = 0x80000000u;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+// The same from values that are wave-uniform but not provably so to the compiler (a tile index that went through a
+// loop and a division): without the hint every load through the descriptor becomes a loop over the distinct
+// descriptors among the lanes, and the wait-count bookkeeping around such loops falls back to "wait for everything".
+__device__ __forceinline__ rsrc_t make_rsrc_uniform(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return make_rsrc(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo), (unsigned)__builtin_amdgcn_readfirstlane(bytes));
+}
 __device__ __forceinline__ uint4 load16(rsrc_t r, unsigned voff, unsigned soff) {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant in
+// every iteration's own code (register arrays indexed by it are then split into registers whatever the optimiser
+// makes of the loop).
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // WAVES = 4: the tile above.  WAVES = 8 (layers with more than 64 output channels): 128 output channels per
@@ -255,7 +275,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
         for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // ---- epilogue operands, loaded during the last multiply phase -----------------------------------------
-    float sc[4], bs[4];
+    // (The bias stays in its 16 bits until the epilogue: widened where it is loaded - inside the branch on g.bias - each
+    // of the four loads would be waited for on the spot, four memory round trips in a row per workgroup.)
+    float sc[4];
+    unsigned bs[4];
     float4 nz[4];
     uint2 rx[4][4];
     const int ch0 = m0 + 64 * half + lrow;
@@ -273,7 +296,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
         for (int m = 0; m < 4; m++) {
             const int ch = min(ch0 + 16 * m, g.co - 1);
             sc[m] = g.out_scale ? g.out_scale[n * g.co + ch] : 1.f;
-            bs[m] = g.bias ? Elem<T>::load(((const T*)g.bias)[ch]) : 0.f;
+            bs[m] = g.bias ? __builtin_bit_cast(unsigned short, ((const T*)g.bias)[ch]) : (unsigned short)0;   // widened in the epilogue
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -336,6 +359,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
     // ---- epilogue: straight-line arithmetic (scale 1, noise 0, bias 0, slope 1, clamp +-inf are no-ops) -------
     const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
     float red[4] = {0.f, 0.f, 0.f, 0.f};
+    const float bsf[4] = {lo16<T>(bs[0]), lo16<T>(bs[1]), lo16<T>(bs[2]), lo16<T>(bs[3])};
     T* __restrict__ y = (T*)g.y;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -347,7 +371,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
             red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float e = v[r] * sc[m] + nzj[r] + bs[m];
+                float e = v[r] * sc[m] + nzj[r] + bsf[m];
                 e = (e > 0.f) ? e : e * g.slope;
                 v[r] = fminf(fmaxf(e * g.gain, -g.hi), g.hi);
             }
@@ -389,7 +413,7 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
     constexpr int kWChunk = 9 * BMW * kRow;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_w = smem;                             // [chunk][tap][BMW][32 channels]
-    unsigned char* s_in = smem + CHUNKS * kWChunk;         // [chunk][footprint pixel][32 channels]
+    unsigned char* s_in = smem + CHUNKS * kWChunk;         // [chunk][footprint pixel][32 channels], kImage bytes per chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
@@ -409,9 +433,13 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
     // (an item's row and packet inside the footprint, its place in the LDS image) is decided here; per tile a lane
     // decides once per item whether the packet lies in the image (else its offset is kOutside: the load returns zeros).
     const int cg = tid & 15, slot0 = tid >> 4;
-    constexpr int STEPS = G::STEPS;
-    constexpr bool LAST_PARTIAL = (G::ITEMS % 16) != 0;
-    const bool last_item = !LAST_PARTIAL || slot0 + 16 * (STEPS - 1) < G::ITEMS;
+    // Every lane moves STEPS items; the 16 STEPS item slots are a few more than the footprint has items, and the image
+    // of a chunk is padded to hold them all (kImage): the surplus items load zeros (kOutside) and are written behind the
+    // footprint like any other.  (Skipping them was a branch around the last item's LDS writes - and around the wait
+    // for its two loads: for the compiler those stayed in flight in the wave that skipped, and the next write to their
+    // registers, the plan of the tile after, waited for everything outstanding, the previous tile's stores included:
+    // 2,400 cycles per tile.)
+    constexpr int STEPS = G::STEPS, kImage = G::kInPadded;
     int item_ry[STEPS], item_px[STEPS];
 #pragma unroll
     for (int q = 0; q < STEPS; q++) {
@@ -423,50 +451,65 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
 #pragma unroll
     for (int jp = 0; jp < 4; jp++) st_addr[jp] = slot0 * 8 * kRow + swz(2 * jp, cg * 4);
     const unsigned plane_bytes = (unsigned)plane * 2u;
-    uint4 va[CHUNKS][STEPS], vb[CHUNKS][STEPS];
+    uint4 va[CHUNKS * STEPS], vb[CHUNKS * STEPS];      // [chunk][item]
     float s0[CHUNKS], s1[CHUNKS];
     auto decode = [&](int unit, int& n, int& a0, int& b0) {
+        unit = __builtin_amdgcn_readfirstlane(unit);      // (uniform: said once, so that what follows stays scalar)
         const int tb = unit % g.tiles_b; unit /= g.tiles_b;
         const int ta = unit % g.tiles_a;
         n = unit / g.tiles_a;
         a0 = ta * TH; b0 = tb * TW;
     };
-    auto fetch = [&](int unit) {
+    // A tile's loads: where its packets lie and the descriptors of its chunks (fetch_plan), then the loads themselves,
+    // dealt over the CHUNKS x 9 taps of the multiply phase of the tile before (fetch_part): issued as one batch they
+    // queue in the texture path - 8,000 cycles per tile for 64 -> 64 channels at 512^2, each 16-byte packet of a lane
+    // pulling in a 128-byte line of which the tile uses 96 bytes at most - and the wave that issues them stands still
+    // for that long; between the taps the same queue drains beside the matrix instructions.  A tile that does not exist
+    // (after a workgroup's last) is planned with every packet outside the image: its loads return zeros without a
+    // memory access, and the tile loop needs no branch inside the multiply phase.
+    unsigned voff[STEPS];
+    rsrc_t d_x[CHUNKS], d_s[CHUNKS];
+    auto fetch_plan = [&](int unit, bool exists) {
         int n, a0, b0;
         decode(unit, n, a0, b0);
-        const T* xs = (const T*)g.x + (unsigned)(n * g.ci * plane);
         const int iy_first = a0 * STEP + g.dy0, px_first = b0 * STEP + g.px_shift;
-        unsigned voff[STEPS];
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
             const int iy = iy_first + item_ry[q], px0 = px_first + item_px[q];
-            const bool ok = iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
+            const bool ok = exists && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
             voff[q] = ok ? (unsigned)(2 * cg * plane + iy * g.wid + px0) * 2u : kOutside;
         }
+        n = exists ? n : 0;
+        const T* xs = (const T*)g.x + (unsigned)(n * g.ci * plane);
 #pragma unroll
         for (int ch = 0; ch < CHUNKS; ch++) {
-            const int left = min(KCH, g.ci - ch * KCH);
-            const rsrc_t rx = make_rsrc(xs + (size_t)ch * KCH * plane, (unsigned)max(left, 0) * plane_bytes);
-#pragma unroll
-            for (int q = 0; q < STEPS; q++) {
-                va[ch][q] = load16(rx, voff[q], 0);
-                vb[ch][q] = load16(rx, voff[q], plane_bytes);
-            }
-            if constexpr (MOD) {
-                const rsrc_t rs = make_rsrc(g.in_scale + (size_t)n * g.ci + ch * KCH, (unsigned)max(left, 0) * 4u);
-                s0[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 0, 0));
-                s1[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 4, 0));
-            }
+            const int left = max(min(KCH, g.ci - ch * KCH), 0);
+            d_x[ch] = make_rsrc_uniform(xs + (size_t)ch * KCH * plane, (unsigned)left * plane_bytes);
+            if constexpr (MOD) d_s[ch] = make_rsrc_uniform(g.in_scale + (size_t)n * g.ci + ch * KCH, (unsigned)left * 4u);
         }
+    };
+    constexpr int kTaps = CHUNKS * 9, kLoads = CHUNKS * STEPS * 2;     // 16-byte loads of a tile per lane
+    auto fetch_part = [&](auto tap) __attribute__((always_inline)) {   // tap: std::integral_constant, 0 .. kTaps - 1
+        constexpr int t = decltype(tap)::value;
+        static_for<kLoads>([&](auto load) __attribute__((always_inline)) {
+            // load l: chunk l / (2 STEPS), item (l / 2) % STEPS, channel 2 cg + (l & 1)
+            constexpr int l = decltype(load)::value, ch = l / (2 * STEPS), q = (l >> 1) % STEPS;
+            if constexpr ((l * kTaps) / kLoads == t) {
+                if constexpr (l & 1) vb[l >> 1] = load16(d_x[ch], voff[q], plane_bytes);
+                else va[l >> 1] = load16(d_x[ch], voff[q], 0);
+            }
+        });
+        if constexpr (MOD && t % 9 == 4) s0[t / 9] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s[t / 9], cg * 8, 0, 0));
+        if constexpr (MOD && t % 9 == 5) s1[t / 9] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s[t / 9], cg * 8, 4, 0));
     };
     auto commit = [&]() {
 #pragma unroll
         for (int ch = 0; ch < CHUNKS; ch++)
 #pragma unroll
             for (int q = 0; q < STEPS; q++) {
-                if (LAST_PARTIAL && q == STEPS - 1 && !last_item) continue;
-                const unsigned wa[4] = {va[ch][q].x, va[ch][q].y, va[ch][q].z, va[ch][q].w};
-                const unsigned wb[4] = {vb[ch][q].x, vb[ch][q].y, vb[ch][q].z, vb[ch][q].w};
+                const uint4 pa = va[ch * STEPS + q], pb = vb[ch * STEPS + q];
+                const unsigned wa[4] = {pa.x, pa.y, pa.z, pa.w};
+                const unsigned wb[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
                 for (int jp = 0; jp < 4; jp++) {
                     unsigned e0, e1;
@@ -477,7 +520,7 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
                         e0 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x05040100u);
                         e1 = __builtin_amdgcn_perm(wb[jp], wa[jp], 0x07060302u);
                     }
-                    unsigned char* dst = s_in + ch * G::kInBytes + st_addr[jp] + q * (16 * 8 * kRow);
+                    unsigned char* dst = s_in + ch * kImage + st_addr[jp] + q * (16 * 8 * kRow);
                     *reinterpret_cast<unsigned*>(dst) = e0;
                     *reinterpret_cast<unsigned*>(dst + kRow) = e1;
                 }
@@ -492,6 +535,15 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
     const int ch0 = lrow;
     const int ch_stride = 16 * g.oh * g.ow;
     T* __restrict__ y = (T*)g.y;
+    // The bias is the same for every tile: loaded and widened once.  (Inside the tile loop the conversion made the
+    // compiler wait for the 16-bit load on the spot - with every load and store the wave had in flight, the next
+    // tile's packets included: four memory round trips per tile, 10,000 of its 22,000 cycles.)
+    float bs[M_TILES];
+#pragma unroll
+    for (int m = 0; m < M_TILES; m++) {
+        const unsigned short bits = g.bias ? __builtin_bit_cast(unsigned short, ((const T*)g.bias)[min(ch0 + 16 * m, g.co - 1)]) : (unsigned short)0;
+        bs[m] = lo16<T>(bits);
+    }
 
     // Workgroups are dealt to the 8 XCDs round-robin; each XCD (own L2) takes a contiguous range of the tiles and its
     // workgroups walk it together in raster order, so that the halo rows and the packets shared by neighbouring tiles
@@ -499,17 +551,32 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
     const int xcd = blockIdx.x & 7, per_xcd = (units + 7) >> 3, stride = gridDim.x >> 3;
     const int unit_end = min(units, (xcd + 1) * per_xcd);
     int unit = xcd * per_xcd + (blockIdx.x >> 3);
-    if (unit < unit_end) fetch(unit);
+    if (unit < unit_end) {     // a workgroup's first tile: all at once
+        fetch_plan(unit, true);
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ch++) {
+#pragma unroll
+            for (int q = 0; q < STEPS; q++) {
+                va[ch * STEPS + q] = load16(d_x[ch], voff[q], 0);
+                vb[ch * STEPS + q] = load16(d_x[ch], voff[q], plane_bytes);
+            }
+            if constexpr (MOD) {
+                s0[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s[ch], cg * 8, 0, 0));
+                s1[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s[ch], cg * 8, 4, 0));
+            }
+        }
+    }
     for (; unit < unit_end; unit += stride) {
         int n, a0, b0;
         decode(unit, n, a0, b0);
         __syncthreads();   // everyone is done reading the previous tile (and, the first time, the weights are in place)
         commit();
         __syncthreads();
-        if (unit + stride < unit_end) fetch(unit + stride);   // next tile: in flight during this tile's multiply phase
+        fetch_plan(unit + stride, unit + stride < unit_end);
 
-        // ---- epilogue operands of this tile, loaded ahead of the multiply phase ------------------------------------
-        float sc[M_TILES], bs[M_TILES];
+        // ---- epilogue operands of this tile, loaded ahead of the multiply phase - and ahead of the next tile's
+        // packets: loads return in order, so the epilogue's wait for its operands leaves those in flight ---------------
+        float sc[M_TILES];
         float4 nz[4];
         uint2 rx[4][M_TILES];
         unsigned off0[4];
@@ -518,7 +585,6 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
         for (int m = 0; m < M_TILES; m++) {
             const int ch = min(ch0 + 16 * m, g.co - 1);
             sc[m] = g.out_scale ? g.out_scale[n * g.co + ch] : 1.f;
-            bs[m] = g.bias ? Elem<T>::load(((const T*)g.bias)[ch]) : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -534,8 +600,8 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
                     rx[j][m] = *reinterpret_cast<const uint2*>((const T*)g.reduce_x + off0[j] + m * ch_stride);
             }
         }
-
-        // ---- multiply: chunks x 9 taps, fragments of the next tap read while this one multiplies -------------------
+        // ---- multiply: chunks x 9 taps, fragments of the next tap read while this one multiplies; the next tile's
+        // loads go out between the taps ---------------------------------------------------------------------------
         f32x4_t acc[M_TILES][4];
 #pragma unroll
         for (int m = 0; m < M_TILES; m++)
@@ -550,19 +616,20 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = brow[j] + ky * LWP + kx;
-                b[j] = *reinterpret_cast<const uint4*>(s_in + ch * G::kInBytes + row * kRow + (((lgrp ^ (row >> 1)) & 3) << 4));
+                b[j] = *reinterpret_cast<const uint4*>(s_in + ch * kImage + row * kRow + (((lgrp ^ (row >> 1)) & 3) << 4));
             }
         };
         read_tap(0, fa[0], fb[0]);
-#pragma unroll
-        for (int t = 0; t < CHUNKS * 9; t++) {
-            if (t + 1 < CHUNKS * 9) read_tap(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+        static_for<kTaps>([&](auto tap) __attribute__((always_inline)) {
+            constexpr int t = decltype(tap)::value;
+            if constexpr (t + 1 < kTaps) read_tap(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+            fetch_part(tap);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int m = 0; m < M_TILES; m++) Mma16<T>::run(fb[t & 1][j], fa[t & 1][m], acc[m][j]);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
 
         // ---- epilogue -------------------------------------------------------------------------------------------
         float red[M_TILES];
@@ -649,7 +716,7 @@ int compute_units() {   // of the current device; asked once per process and dev
 
 template <class T, int CHUNKS, int M_TILES, int STEP, bool MOD>
 static int launch_resident_mod(const Conv3x3Args& g, int64_t units, hipStream_t stream) {
-    constexpr size_t lds = (size_t)CHUNKS * (9 * 16 * M_TILES * kRow + Geo<STEP>::kInBytes);
+    constexpr size_t lds = (size_t)CHUNKS * (9 * 16 * M_TILES * kRow + Geo<STEP>::kInPadded);
     static_assert(lds <= 160 * 1024, "weights and tile do not fit the LDS of a CU");
     auto kernel = conv3x3_resident_kernel<T, CHUNKS, M_TILES, STEP, MOD>;
     hipError_t e = allow_large_lds((const void*)kernel);

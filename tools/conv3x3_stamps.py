@@ -15,6 +15,16 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (64 * 2 * 8))()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 assert lib.sg_debug_conv3x3_stamps(buf) == 0
+if os.environ.get('RESIDENT'):      # the weights-resident kernel (tools/ablation/resident_stamps_build.py): waves 0 and 2
+    names = ['barrier 1', 'commit', 'barrier 2', 'plan + operands', 'multiply + loads', 'epilogue']
+    for half in (0, 1):
+        rows = [[buf[(wg * 2 + half) * 8 + k] for k in range(8)] for wg in range(64)]
+        rows = [r for r in rows if r[7] > 0]
+        med = lambda k: sorted(r[k] for r in rows)[len(rows) // 2]
+        tiles = med(7)
+        print(f'wave {2 * half}: {tiles} tiles, whole kernel {med(6)} cycles = {med(6) / tiles:.0f} per tile;  ' +
+              '  '.join(f'{names[k]} {med(k) / tiles:6.0f}' for k in range(6)))
+    sys.exit(0)
 names = ['barrier 1', 'commit', 'barrier 2', 'fetch', 'multiply']
 for half in (0, 1):
     rows = [[buf[(wg * 2 + half) * 8 + k] for k in range(8)] for wg in range(64)]
