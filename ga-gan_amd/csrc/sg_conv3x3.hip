@@ -97,6 +97,25 @@ template <class T> __device__ __forceinline__ float lo16(unsigned w) { return Pa
 template <class T> __device__ __forceinline__ float hi16(unsigned w) { return Pair<T>::hi(w); }
 template <class T> __device__ __forceinline__ unsigned pack16(float a, float b) { return Pair<T>::pack(a, b); }
 
+// The layer epilogue on four consecutive pixels of one channel, two at a time (packed fp32 instructions: half the
+// vector instructions of the scalar form, which is what a persistent workgroup with one wave per SIMD spends its
+// epilogue on): x * scale + noise, + bias, leaky ReLU as max(z, z * slope) (0 <= slope <= 1, checked by the
+// dispatcher), gain, clamp as a median of three; scale 1, noise 0, bias 0, slope 1, clamp +-inf are no-ops.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ uint2 finish4(const f32x4_t& a, float sc, f32x2_t nz01, f32x2_t nz23, float bs, float slope, float gain, float hi) {
+    f32x2_t e0 = {a[0], a[1]}, e1 = {a[2], a[3]};
+    e0 = e0 * f32x2_t{sc, sc} + nz01;
+    e1 = e1 * f32x2_t{sc, sc} + nz23;
+    e0 += f32x2_t{bs, bs};
+    e1 += f32x2_t{bs, bs};
+    const f32x2_t s0 = e0 * f32x2_t{slope, slope}, s1 = e1 * f32x2_t{slope, slope};
+    e0 = f32x2_t{__builtin_fmaxf(e0[0], s0[0]), __builtin_fmaxf(e0[1], s0[1])} * f32x2_t{gain, gain};
+    e1 = f32x2_t{__builtin_fmaxf(e1[0], s1[0]), __builtin_fmaxf(e1[1], s1[1])} * f32x2_t{gain, gain};
+    return make_uint2(pack16<T>(__builtin_amdgcn_fmed3f(e0[0], -hi, hi), __builtin_amdgcn_fmed3f(e0[1], -hi, hi)),
+                      pack16<T>(__builtin_amdgcn_fmed3f(e1[0], -hi, hi), __builtin_amdgcn_fmed3f(e1[1], -hi, hi)));
+}
+
 // Buffer addressing: a resource descriptor bounds every access to `bytes` from its base; a byte offset at or beyond the
 // bound reads zeros.  A packet outside the image (or a channel beyond the last) therefore costs no branch and no
 // select in the loop: its offset is set to kOutside once, or the bound is drawn in front of it.
@@ -363,19 +382,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
     T* __restrict__ y = (T*)g.y;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const float nzj[4] = {nz[j].x * noise_gain, nz[j].y * noise_gain, nz[j].z * noise_gain, nz[j].w * noise_gain};
+        const f32x2_t nz01 = {nz[j].x * noise_gain, nz[j].y * noise_gain}, nz23 = {nz[j].z * noise_gain, nz[j].w * noise_gain};
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             if (!inside[j] || ch0 + 16 * m >= g.co) continue;
-            float v[4] = {acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
-            red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float e = v[r] * sc[m] + nzj[r] + bsf[m];
-                e = (e > 0.f) ? e : e * g.slope;
-                v[r] = fminf(fmaxf(e * g.gain, -g.hi), g.hi);
-            }
-            *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = make_uint2(pack16<T>(v[0], v[1]), pack16<T>(v[2], v[3]));
+            const f32x4_t v = acc[m][j];
+            if (g.reduce_out)
+                red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
+            *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = finish4<T>(v, sc[m], nz01, nz23, bsf[m], g.slope, g.gain, g.hi);
         }
     }
     if (g.reduce_out) {
@@ -398,6 +412,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
 }
 
 
+// The weights-resident kernel at unit stride hands a lane eight consecutive pixels of a channel (16-byte stores): row i
+// of its pixel tile j is pixel 8 (i / 4) + 4 (j & 1) + i % 4 of the tile row, not 16 (j & 1) + i.  The 16 image rows a
+// ds_read_b128 lane group then touches are four runs of four, eight apart, and the slot swizzle that keeps them on 16
+// different bank slots takes bits 1 and 3 of the row (bits 1 and 2 for 16 rows in a run).
+template <bool PERM> __device__ __forceinline__ int slot_swizzle(int row) {
+    return PERM ? (((row >> 1) & 1) | ((row >> 2) & 2)) : ((row >> 1) & 3);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Narrow layers (at most 64 input and 64 output channels: the 256^2 ... 1024^2 layers, whose arithmetic
 // intensity puts them at or near the HBM roofline): the whole weight tensor (<= 72 KB) stays in LDS for the
@@ -410,6 +432,7 @@ template <class T, int CHUNKS, int M_TILES, int STEP, bool MOD>
 __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES <= 2) ? 2 : 1) conv3x3_resident_kernel(Conv3x3Args g, int units) {
     using G = Geo<STEP>;
     constexpr int NV = G::NV, LWP = G::LWP, BMW = 16 * M_TILES;
+    constexpr bool PERM = (STEP == 1);      // a lane's outputs: 8 consecutive pixels (PERM) or 4 + 4 sixteen apart
     constexpr int kWChunk = 9 * BMW * kRow;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_w = smem;                             // [chunk][tap][BMW][32 channels]
@@ -449,7 +472,10 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
     }
     int st_addr[4];
 #pragma unroll
-    for (int jp = 0; jp < 4; jp++) st_addr[jp] = slot0 * 8 * kRow + swz(2 * jp, cg * 4);
+    for (int jp = 0; jp < 4; jp++) {          // image row slot0 * 8 + 2 jp (the rows of the lane's other items: + 128 q, same swizzle)
+        const int row = slot0 * 8 + 2 * jp;
+        st_addr[jp] = row * kRow + ((((cg >> 2) ^ slot_swizzle<PERM>(row)) & 3) << 4) + (cg & 3) * 4;
+    }
     const unsigned plane_bytes = (unsigned)plane * 2u;
     uint4 va[CHUNKS * STEPS], vb[CHUNKS * STEPS];      // [chunk][item]
     float s0[CHUNKS], s1[CHUNKS];
@@ -469,9 +495,11 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
     // memory access, and the tile loop needs no branch inside the multiply phase.
     unsigned voff[STEPS];
     rsrc_t d_x[CHUNKS], d_s[CHUNKS];
+    int p_n = 0, p_a0 = 0, p_b0 = 0;                       // the planned tile: sample, first output row and column
     auto fetch_plan = [&](int unit, bool exists) {
         int n, a0, b0;
         decode(unit, n, a0, b0);
+        p_n = n; p_a0 = a0; p_b0 = b0;
         const int iy_first = a0 * STEP + g.dy0, px_first = b0 * STEP + g.px_shift;
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
@@ -529,7 +557,10 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
 
     int brow[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * STEP * LWP + ((j & 1) * 16 + lrow) * STEP + g.px_col;
+    for (int j = 0; j < 4; j++) {
+        const int px = PERM ? 8 * (lrow >> 2) + 4 * (j & 1) + (lrow & 3) : (j & 1) * 16 + lrow;   // pixel of tile row i = lrow
+        brow[j] = (2 * wave + (j >> 1)) * STEP * LWP + px * STEP + g.px_col;
+    }
     const int a_lane = lrow * kRow + (((lgrp ^ (lrow >> 1)) & 3) << 4);
     const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
     const int ch0 = lrow;
@@ -567,8 +598,7 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
         }
     }
     for (; unit < unit_end; unit += stride) {
-        int n, a0, b0;
-        decode(unit, n, a0, b0);
+        const int n = p_n, a0 = p_a0, b0 = p_b0;      // (decoded when the tile was planned)
         __syncthreads();   // everyone is done reading the previous tile (and, the first time, the weights are in place)
         commit();
         __syncthreads();
@@ -576,6 +606,8 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
 
         // ---- epilogue operands of this tile, loaded ahead of the multiply phase - and ahead of the next tile's
         // packets: loads return in order, so the epilogue's wait for its operands leaves those in flight ---------------
+        // (PERM: a lane holds pixels b .. b + 7 of output row a0 + 2 wave + h, h = 0, 1 - the first four from pixel tile 2 h,
+        // the others from 2 h + 1; else pixels b .. b + 3 of tile j, b = 16 (j & 1) + 4 lgrp)
         float sc[M_TILES];
         float4 nz[4];
         uint2 rx[4][M_TILES];
@@ -588,16 +620,31 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int a = a0 + 2 * wave + (j >> 1), b = b0 + (j & 1) * 16 + 4 * lgrp;
+            const int a = a0 + 2 * wave + (j >> 1), b = b0 + (PERM ? 8 * lgrp + 4 * (j & 1) : (j & 1) * 16 + 4 * lgrp);
             inside[j] = a < g.oh && b < g.ow;
             off0[j] = (unsigned)(((n * g.co + ch0) * g.oh + a) * g.ow + b);
             nz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.noise && inside[j]) nz[j] = *reinterpret_cast<const float4*>(g.noise + n * g.noise_stride + a * g.ow + b);
+        }
+        if (g.reduce_out) {     // (one scalar branch around the lot: a layer without the reduction pays nothing per load)
 #pragma unroll
             for (int m = 0; m < M_TILES; m++) {
-                rx[j][m] = make_uint2(0, 0);
-                if (g.reduce_out && inside[j] && ch0 + 16 * m < g.co)
-                    rx[j][m] = *reinterpret_cast<const uint2*>((const T*)g.reduce_x + off0[j] + m * ch_stride);
+                if constexpr (PERM) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        uint4 v = make_uint4(0, 0, 0, 0);
+                        if (inside[2 * h] && ch0 + 16 * m < g.co) v = *reinterpret_cast<const uint4*>((const T*)g.reduce_x + off0[2 * h] + m * ch_stride);
+                        rx[2 * h][m] = make_uint2(v.x, v.y);
+                        rx[2 * h + 1][m] = make_uint2(v.z, v.w);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        rx[j][m] = make_uint2(0, 0);
+                        if (inside[j] && ch0 + 16 * m < g.co)
+                            rx[j][m] = *reinterpret_cast<const uint2*>((const T*)g.reduce_x + off0[j] + m * ch_stride);
+                    }
+                }
             }
         }
         // ---- multiply: chunks x 9 taps, fragments of the next tap read while this one multiplies; the next tile's
@@ -616,7 +663,7 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = brow[j] + ky * LWP + kx;
-                b[j] = *reinterpret_cast<const uint4*>(s_in + ch * kImage + row * kRow + (((lgrp ^ (row >> 1)) & 3) << 4));
+                b[j] = *reinterpret_cast<const uint4*>(s_in + ch * kImage + row * kRow + (((lgrp ^ slot_swizzle<PERM>(row)) & 3) << 4));
             }
         };
         read_tap(0, fa[0], fb[0]);
@@ -636,20 +683,26 @@ __global__ void __launch_bounds__(kThreads, (CHUNKS == 1 && STEP == 1 && M_TILES
 #pragma unroll
         for (int m = 0; m < M_TILES; m++) red[m] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float nzj[4] = {nz[j].x * noise_gain, nz[j].y * noise_gain, nz[j].z * noise_gain, nz[j].w * noise_gain};
+        for (int j = 0; j < 4; j += (PERM ? 2 : 1)) {
+            f32x2_t nz01[2], nz23[2];
+#pragma unroll
+            for (int k = 0; k < (PERM ? 2 : 1); k++) {
+                nz01[k] = f32x2_t{nz[j + k].x * noise_gain, nz[j + k].y * noise_gain};
+                nz23[k] = f32x2_t{nz[j + k].z * noise_gain, nz[j + k].w * noise_gain};
+            }
 #pragma unroll
             for (int m = 0; m < M_TILES; m++) {
-                if (!inside[j] || ch0 + 16 * m >= g.co) continue;
-                float v[4] = {acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
-                red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
+                if (!inside[j] || ch0 + 16 * m >= g.co) continue;       // (PERM: the width is a multiple of 8 - the pair is inside or not)
+                uint2 out[2];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float e = v[r] * sc[m] + nzj[r] + bs[m];
-                    e = (e > 0.f) ? e : e * g.slope;
-                    v[r] = fminf(fmaxf(e * g.gain, -g.hi), g.hi);
+                for (int k = 0; k < (PERM ? 2 : 1); k++) {
+                    const f32x4_t v = acc[m][j + k];
+                    const uint2 r = rx[j + k][m];
+                    if (g.reduce_out) red[m] += v[0] * lo16<T>(r.x) + v[1] * hi16<T>(r.x) + v[2] * lo16<T>(r.y) + v[3] * hi16<T>(r.y);
+                    out[k] = finish4<T>(v, sc[m], nz01[k], nz23[k], bs[m], g.slope, g.gain, g.hi);
                 }
-                *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = make_uint2(pack16<T>(v[0], v[1]), pack16<T>(v[2], v[3]));
+                if constexpr (PERM) *reinterpret_cast<uint4*>(y + off0[j] + m * ch_stride) = make_uint4(out[0].x, out[0].y, out[1].x, out[1].y);
+                else *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = out[0];
             }
         }
         if (g.reduce_out) {
@@ -680,6 +733,7 @@ bool conv3x3_eligible(const sg_conv2d_params& p) {
     const sg_conv2d_phase& ph = p.phase[0];
     if (ph.nky != 3 || ph.nkx != 3 || ph.oy0 != 0 || ph.ox0 != 0 || ph.w_offset != 0) return false;
     if (p.ow < TW || p.oh < 5) return false;                      // smaller outputs would leave most of the 8 x 32 tile empty
+    if (p.act == 3 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;   // the epilogue takes the leaky ReLU as a max
     if (p.w_in % 8 != 0 || p.ow % 4 != 0 || p.ci % 8 != 0) return false;
     if ((int64_t)p.ci * p.h * p.w_in >= (int64_t)1 << 30) return false;   // a sample's bytes bound the buffer offsets (< 2^31)
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
@@ -695,7 +749,8 @@ bool conv3x3_eligible(const sg_conv2d_params& p) {
 
 bool conv3x3_resident(const sg_conv2d_params& p) {   // among the eligible geometries: the weights-resident kernel
     if (p.in_step == 2) return p.ci <= KCH && p.co <= BM && p.co > 32;
-    return p.ci <= 2 * KCH && p.co <= BM;
+    // (at unit stride it moves eight output pixels per lane and access)
+    return p.ci <= 2 * KCH && p.co <= BM && p.ow % 8 == 0 && aligned16(p.y) && aligned16(p.reduce_x);
 }
 
 int conv3x3_reduce_rows(const sg_conv2d_params& p) {

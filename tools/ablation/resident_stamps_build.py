@@ -9,13 +9,12 @@ def rep(old, new):
     global src
     assert src.count(old) == 1, old[:50]
     src = src.replace(old, new)
-rep("    for (; unit < unit_end; unit += stride) {\n        int n, a0, b0;\n        decode(unit, n, a0, b0);\n        __syncthreads();   // everyone is done reading the previous tile (and, the first time, the weights are in place)\n        commit();\n        __syncthreads();\n",
+rep("    for (; unit < unit_end; unit += stride) {\n        const int n = p_n, a0 = p_a0, b0 = p_b0;      // (decoded when the tile was planned)\n        __syncthreads();   // everyone is done reading the previous tile (and, the first time, the weights are in place)\n        commit();\n        __syncthreads();\n",
 '''    unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0}, tiles_done = 0;
     auto now = [] { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
     const unsigned long long t_begin = now();
     for (; unit < unit_end; unit += stride) {
-        int n, a0, b0;
-        decode(unit, n, a0, b0);
+        const int n = p_n, a0 = p_a0, b0 = p_b0;
         const unsigned long long t0 = now();
         __syncthreads();   // everyone is done reading the previous tile (and, the first time, the weights are in place)
         const unsigned long long t1 = now();
