@@ -21,7 +21,10 @@ class EpilogueBwdParams(ctypes.Structure):
     _fields_ = [('dy', ctypes.c_void_p), ('y', ctypes.c_void_p), ('dz', ctypes.c_void_p), ('ep', Epilogue),
                 ('dbias', ctypes.c_void_p), ('dscale', ctypes.c_void_p), ('dnoise_gain', ctypes.c_void_p),
                 ('dtype', ctypes.c_int32), ('n', ctypes.c_int32), ('c', ctypes.c_int32), ('h', ctypes.c_int32),
-                ('w', ctypes.c_int32)]
+                ('w', ctypes.c_int32), ('dnoise_slots', ctypes.c_int32)]
+
+
+NOISE_SLOTS = 256     # addresses the noise-strength gradient is accumulated over (one address takes an atomic per 14 ns)
 
 
 def make_epilogue(n, c, oh, ow, dtype, scale=None, noise=None, noise_gain=None, bias=None, act='linear', alpha=0.2,
@@ -82,12 +85,13 @@ def epilogue_backward(dy, y, want_dbias, want_dscale, want_dnoise_gain, want_dz=
     dz = torch.empty_like(y) if want_dz else None
     dbias = torch.zeros([c], dtype=torch.float32, device=y.device) if want_dbias else None
     dscale = torch.zeros([n, c], dtype=torch.float32, device=y.device) if want_dscale else None
-    dng = torch.zeros([], dtype=torch.float32, device=y.device) if want_dnoise_gain else None
+    dng = torch.zeros([NOISE_SLOTS], dtype=torch.float32, device=y.device) if want_dnoise_gain else None
     if y.numel():
         p = EpilogueBwdParams(dy=_lib.ptr(dy), y=_lib.ptr(y), dz=_lib.ptr(dz), ep=ep, dbias=_lib.ptr(dbias),
-                              dscale=_lib.ptr(dscale), dnoise_gain=_lib.ptr(dng), dtype=_lib.dtype_code(y), n=n, c=c, h=h, w=w)
+                              dscale=_lib.ptr(dscale), dnoise_gain=_lib.ptr(dng), dtype=_lib.dtype_code(y), n=n, c=c, h=h, w=w,
+                              dnoise_slots=NOISE_SLOTS)
         _lib.launch('sg_epilogue_backward', p, y, 'epilogue_bwd_kernel', _lib.nbytes(dy, y, dz))
-    return dz, dbias, dscale, dng
+    return dz, dbias, dscale, (dng.sum() if dng is not None else None)
 
 
 class ConvUp2FirParams(ctypes.Structure):

@@ -197,7 +197,9 @@ const char* sg_upfirdn2d_kernel(const sg_upfirdn2d_params* p, const sg_epilogue*
  *   dz = g * scale[n,c]                                   -> gradient w.r.t. the pre-epilogue value v
  *   dbias[c]      += sum_{n,hw} g                          (float atomics; caller zeroes)
  *   dscale[n,c]   += sum_hw g * v, with v recovered from y: v = (act^-1(y / gain) - noise * *noise_gain - bias[c]) / scale[n,c]
- *   dnoise_gain[0]+= sum g * noise
+ *   sum_k dnoise_gain[k] += sum g * noise               (k < max(dnoise_slots, 1): a workgroup adds its share to one of
+ *                                                        the slots, the gradient is their sum - thousands of float
+ *                                                        atomics on ONE address run one after the other, 14 ns each)
  * (all three accumulated with float atomics: the caller zeroes them).  dz may be NULL: only the reductions are
  * computed then, for callers that hand dy and y to sg_conv2d's input mask instead of materialising dz.
  * No counterpart in the reference's native code: it is the fusion of `bias_act`'s grad=1 kernel
@@ -210,9 +212,10 @@ typedef struct sg_epilogue_bwd_params {
     sg_epilogue ep;       /* the forward's epilogue */
     float* dbias;         /* [c] or NULL */
     float* dscale;        /* [n, c] or NULL (needs ep.scale) */
-    float* dnoise_gain;   /* [1] or NULL (needs ep.noise) */
+    float* dnoise_gain;   /* [max(dnoise_slots, 1)] or NULL (needs ep.noise) */
     int32_t dtype;
     int32_t n, c, h, w;
+    int32_t dnoise_slots; /* floats at dnoise_gain to spread the additions over; 0 or 1: a single one */
 } sg_epilogue_bwd_params;
 
 int sg_epilogue_backward(const sg_epilogue_bwd_params* p, sg_stream_t stream);
