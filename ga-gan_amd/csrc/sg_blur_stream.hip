@@ -39,34 +39,10 @@ template <> struct Pair<__half> {
     }
 };
 
-// A piece outside the plane is read from here instead of being skipped: every load is then issued by every lane, no
-// branch surrounds it, and the wait for a row's pieces is a counted one that leaves the rows requested after it in
-// flight.  (With `ok ? *src : zero` the loads sat in branches of their own, the conversion of a narrow piece moved in
-// beside its load, and the wave waited there for everything it had outstanding - the rows just requested included:
-// two memory round trips per row, hidden by nothing but the other waves of the CU.)
-__device__ __attribute__((aligned(16))) const unsigned kZeroPacket[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-// (both are addresses in global memory; said so - and loaded as a plain vector, not through uint4's copy constructor -
-// or the choice between them makes the load a flat one)
-template <class V, class T> __device__ __forceinline__ V load_global_or_zero(bool ok, const T* src) {
-    typedef const V __attribute__((address_space(1)))* Global;
-    return *(ok ? (Global)(const void*)src : (Global)(const void*)kZeroPacket);
-}
-template <class V, class T> __device__ __forceinline__ V load_or_zero(bool ok, const T* src);
-template <> __device__ __forceinline__ uint4 load_or_zero<uint4, __hip_bfloat16>(bool ok, const __hip_bfloat16* src) {
-    const u32x4_t v = load_global_or_zero<u32x4_t>(ok, src); return make_uint4(v.x, v.y, v.z, v.w);
-}
-template <> __device__ __forceinline__ uint2 load_or_zero<uint2, __hip_bfloat16>(bool ok, const __hip_bfloat16* src) {
-    const u32x2_t v = load_global_or_zero<u32x2_t>(ok, src); return make_uint2(v.x, v.y);
-}
-template <> __device__ __forceinline__ uint4 load_or_zero<uint4, __half>(bool ok, const __half* src) {
-    const u32x4_t v = load_global_or_zero<u32x4_t>(ok, src); return make_uint4(v.x, v.y, v.z, v.w);
-}
-template <> __device__ __forceinline__ uint2 load_or_zero<uint2, __half>(bool ok, const __half* src) {
-    const u32x2_t v = load_global_or_zero<u32x2_t>(ok, src); return make_uint2(v.x, v.y);
-}
-
+// (Pieces outside the plane are read from a packet of zeros - load16_or_zero, load8_or_zero - so that every load is
+// unconditional: with `ok ? *src : zero` the loads sat in branches of their own, the conversion of a narrow piece
+// moved in beside its load, and the wave waited there for everything it had outstanding - the rows just requested
+// included: two memory round trips per row, hidden by nothing but the other waves of the CU.)
 constexpr int kBand = 32;       // output rows of a wave's band
 constexpr int kCols = 512;      // output columns of a wave: 8 per lane
 
@@ -121,9 +97,9 @@ __global__ void __launch_bounds__(256) blur4_stream_kernel(sg_upfirdn2d_params p
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const T* src = (q ? x1 : x0) + off;
-            row.m[q] = load_or_zero<uint4>(m_ok, src);
-            row.l[q] = load_or_zero<uint2>(l_ok, src - 4);
-            row.r[q] = load_or_zero<uint2>(r_ok, src + 8);
+            row.m[q] = load16_or_zero(m_ok, src);
+            row.l[q] = load8_or_zero(l_ok, src - 4);
+            row.r[q] = load8_or_zero(r_ok, src + 8);
         }
     };
 
@@ -281,10 +257,10 @@ __global__ void __launch_bounds__(256) down2_stream_kernel(sg_upfirdn2d_params p
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const T* src = (q ? x1 : x0) + off;
-            row.m[q][0] = load_or_zero<uint4>(m0_ok, src);
-            row.m[q][1] = load_or_zero<uint4>(m1_ok, src + 8);
-            row.l[q] = load_or_zero<uint2>(l_ok, src - 4);
-            row.r[q] = load_or_zero<uint2>(r_ok, src + 16);
+            row.m[q][0] = load16_or_zero(m0_ok, src);
+            row.m[q][1] = load16_or_zero(m1_ok, src + 8);
+            row.l[q] = load8_or_zero(l_ok, src - 4);
+            row.r[q] = load8_or_zero(r_ok, src + 16);
         }
     };
 
@@ -438,9 +414,9 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const T* src = (q ? x1 : x0) + off;
-            row.m[q] = load_or_zero<uint4>(m_ok, src);
-            row.l[q] = load_or_zero<uint2>(l_ok, src - 4);
-            row.r[q] = load_or_zero<uint2>(r_ok, src + 8);
+            row.m[q] = load16_or_zero(m_ok, src);
+            row.l[q] = load8_or_zero(l_ok, src - 4);
+            row.r[q] = load8_or_zero(r_ok, src + 8);
         }
     };
 

@@ -52,6 +52,29 @@ template <> struct Elem<__hip_bfloat16> {
     static __device__ __forceinline__ __hip_bfloat16 store(float v) { return __float2bfloat16(v); }
 };
 
+// Loads that every lane issues: a piece outside the tensor is read from a packet of zeros instead of being skipped.
+// No branch then surrounds the load, the value's first use decides where the wave waits, and that wait is a counted
+// one which leaves the loads issued after it in flight.  (A load inside a branch is waited for by `s_waitcnt vmcnt(0)`
+// wherever the compiler cannot count what came after it - typically at once, when a conversion of the loaded value
+// was moved into the branch - and that wait covers everything the wave has outstanding, prefetches included.)
+static __device__ __attribute__((aligned(16))) const unsigned kZeroPacket[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+typedef unsigned sg_u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned sg_u32x2_t __attribute__((ext_vector_type(2)));
+// (both sources are addresses in global memory; said so - and loaded as a plain vector, not through uint4's copy
+// constructor - or the choice between them makes the load a flat one)
+template <class V> __device__ __forceinline__ V load_global_or_zero(bool ok, const void* src) {
+    typedef const V __attribute__((address_space(1)))* Global;
+    return *(ok ? (Global)src : (Global)(const void*)kZeroPacket);
+}
+__device__ __forceinline__ uint4 load16_or_zero(bool ok, const void* src) {
+    const sg_u32x4_t v = load_global_or_zero<sg_u32x4_t>(ok, src); return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 load8_or_zero(bool ok, const void* src) {
+    const sg_u32x2_t v = load_global_or_zero<sg_u32x2_t>(ok, src); return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ unsigned load4_or_zero(bool ok, const void* src) { return load_global_or_zero<unsigned>(ok, src); }
+__device__ __forceinline__ unsigned short load2_or_zero(bool ok, const void* src) { return load_global_or_zero<unsigned short>(ok, src); }
+
 // A 16-byte packet of T, moved with one dwordx4 access.
 template <class T> struct alignas(16) Pack {
     static constexpr int N = 16 / sizeof(T);

@@ -109,7 +109,8 @@ struct Stage {                                        // what a step's loads lea
     uint4 va[STEPS], vb[STEPS];
     float s0, s1;
     float4 vn;
-    float scg, bsg;
+    float scg;
+    unsigned bsb;                                     // the bias, still in its 16 bits
 };
 
 // RESIDENT: at most 64 input and 32 output channels - the two weight buffers hold the whole composed kernel and are
@@ -183,13 +184,10 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
             int ry, col; bool halo, live;
             slot_geometry(q, ry, col, halo, live);
             const int iy = t.a0 - 1 + ry, px0 = t.b0 - 8 + col;
-            st.va[q] = make_uint4(0, 0, 0, 0);
-            st.vb[q] = make_uint4(0, 0, 0, 0);
-            if (c_ok && live && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid) {
-                const T* src = src0 + iy * g.wid + px0;
-                st.va[q] = *reinterpret_cast<const uint4*>(src);
-                if (two) st.vb[q] = *reinterpret_cast<const uint4*>(src + plane);
-            }
+            const bool ok = c_ok && live && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
+            const T* src = src0 + iy * g.wid + px0;
+            st.va[q] = load16_or_zero(ok, src);                 // (unconditional loads: sg_common.h)
+            st.vb[q] = load16_or_zero(ok && two, src + plane);
         }
         if (!RESIDENT && g.in_scale) {
             st.s0 = c_ok ? g.in_scale[(int64_t)t.n * g.ci + c] : 0.f;
@@ -203,7 +201,7 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
             }
             const bool ch_ok = t.m0 + ch < g.co;
             st.scg = (g.scale && ch_ok) ? g.scale[(int64_t)t.n * g.co + t.m0 + ch] : 1.f;
-            st.bsg = (g.bias && ch_ok) ? Pair<T>::lo((unsigned)__builtin_bit_cast(unsigned short, ((const T*)g.bias)[t.m0 + ch])) : 0.f;
+            st.bsb = load2_or_zero(g.bias && ch_ok, (const T*)g.bias + t.m0 + ch);     // widened when it is committed
         }
     };
     uint4 vw[RESIDENT ? 1 : WROUNDS];
@@ -273,7 +271,7 @@ __global__ void __launch_bounds__(kThreads, 1) conv_up2_fir_kernel(UpFirArgs g) 
         if (p.c == 0) {
             if (g.noise && tid < kNoise / 4) *reinterpret_cast<float4*>(s_noise + (p.idx % 3) * kNoise + 4 * tid) = st.vn;
             nscg = st.scg * g.gain;
-            nbsg = st.bsg * g.gain;
+            nbsg = Pair<T>::lo(st.bsb) * g.gain;
         }
     };
 
