@@ -28,7 +28,7 @@ from .upfirdn2d import _get_filter_size
 
 
 MIN_FUSED_PIXELS_F32 = 1 << 15
-ONE_PASS_UP_MAX_CHANNELS = 128
+ONE_PASS_UP_MAX_CHANNELS = 64
 
 
 def supported(x, w, up, down, groups=1):
@@ -65,9 +65,9 @@ def _filter_taps(f):
 
 def _one_pass_up(x, w, f, k, blur_pad, extra, act, alpha, gain):
     """(composed weights, vertical taps) when the one-pass kernel covers this up-sampling layer, else None."""
-    # Beyond 128 input channels the layer is bound by its matrix work, which the one-pass form doubles (18 tap
-    # combinations instead of 9): there the two passes are faster (256 -> 128 channels at 128^2, 32 samples: 0.96 ms
-    # against 1.11 ms; 128 -> 64 at 256^2: 1.32 against 1.27; 64 -> 32 at 512^2: 2.36 against 1.46).
+    # From 128 input channels the layer is bound by its matrix work, which the one-pass form doubles (18 tap
+    # combinations instead of 9): there the two passes are faster (256 -> 128 channels at 128^2, 32 samples: 0.85 ms
+    # against 1.10 ms; 128 -> 64 at 256^2: 1.20 against 1.28; 64 -> 32 at 512^2: 2.08 against 1.43).
     if x.shape[1] > ONE_PASS_UP_MAX_CHANNELS:
         return None
     if k != 3 or tuple(blur_pad) != (1, 1 - extra, 1, 1) or not _layer.conv_up2_fir_supported(x, w.shape[0], act, alpha, gain):

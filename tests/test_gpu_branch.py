@@ -98,5 +98,8 @@ def test_discriminator_block_with_and_without_branch():
     (ya, ga), (yb, gb) = results
     assert torch.equal(ya, yb)
     assert torch.equal(ga[0], gb[0])                       # the block input's gradient: the same arithmetic in one pass
-    for a, b in zip(ga[1:], gb[1:]):                        # weight gradients are summed with float atomics: order varies
-        assert torch.allclose(a.float(), b.float(), rtol=1e-3, atol=1e-3 * float(b.abs().max()))
+    # Weight gradients are summed with float atomics, in an order that varies from launch to launch, and those of the
+    # 16-bit layers are then rounded to bfloat16 (the type the weight was cast to): a sum that differs in its last
+    # float32 bits can land on the other side of a rounding boundary, one bfloat16 ulp (2^-7 of the largest element).
+    for a, b in zip(ga[1:], gb[1:]):
+        assert torch.allclose(a.float(), b.float(), rtol=2.0 ** -7, atol=2.0 ** -7 * float(b.abs().max()))

@@ -54,8 +54,10 @@ def test_graph_replay_matches_host_launches():
         assert set(host) == set(replay), phase.name
         for n in host:
             scale = max(float(host[n].abs().max()), 1e-6)
-            # float atomics in the weight gradients: the order of additions varies from run to run
-            assert float((host[n] - replay[n]).abs().max()) <= 1e-3 * scale, (phase.name, n, float((host[n] - replay[n]).abs().max()) / scale)
+            # float atomics in the weight and style gradients: the order of additions varies from run to run, and the
+            # style gradients of the 4 x 4 layers are small differences of large sums (seen: 4e-3 of the largest element
+            # of synthesis.b4.conv1.affine.weight once in a dozen runs; a replay that read stale memory is off by O(1))
+            assert float((host[n] - replay[n]).abs().max()) <= 1e-2 * scale, (phase.name, n, float((host[n] - replay[n]).abs().max()) / scale)
             checked += 1
     assert checked > 50
 
