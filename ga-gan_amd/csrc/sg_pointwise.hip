@@ -76,7 +76,7 @@ template <class T> __device__ __forceinline__ float unpack_hi(unsigned v) {
     return Elem<T>::load(__builtin_bit_cast(T, (unsigned short)(v >> 16)));
 }
 
-template <class T, int NTL>   // NTL: 16-channel output tiles per workgroup
+template <class T, int NTL, bool ADD>   // NTL: 16-channel output tiles per workgroup; ADD: an addend comes with the output
 __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(PwArgs a) {
     constexpr int BN = 16 * NTL;
     constexpr int W_IT = (BN * 4 + kThreads - 1) / kThreads;   // 16-byte weight pieces per lane and chunk
@@ -99,8 +99,11 @@ __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(P
     const int chunks = a.ci / KCH;
     const int nbuf = chunks > 1 ? 2 : 1;
 
-    unsigned char* s_x[2] = {smem, smem + (nbuf - 1) * kXBytes};
-    unsigned char* s_w[2] = {smem + nbuf * kXBytes, smem + nbuf * kXBytes + (nbuf - 1) * kWBytes};
+    // (the buffers are named by offsets into smem: pointers picked from an array at run time lose their address space,
+    // and every access through them becomes a flat one that waits for the global loads in flight as well)
+    const int x_second = (nbuf - 1) * kXBytes, w_first = nbuf * kXBytes, w_second = (nbuf - 1) * kWBytes;
+    auto s_x = [&](int buf) __attribute__((always_inline)) { return smem + buf * x_second; };
+    auto s_w = [&](int buf) __attribute__((always_inline)) { return smem + w_first + buf * w_second; };
 
     const T* __restrict__ x = (const T*)a.x;
     const T* __restrict__ w = (const T*)a.w;
@@ -127,15 +130,15 @@ __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(P
     auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < 4; it++)
-            *reinterpret_cast<uint4*>(s_x[buf] + (it * 8 + xrow) * kXPitch + xpk * 16) = xreg[it];
+            *reinterpret_cast<uint4*>(s_x(buf) + (it * 8 + xrow) * kXPitch + xpk * 16) = xreg[it];
 #pragma unroll
         for (int k = 0; k < W_IT; k++) {
             const int e = tid + k * kThreads, row = e >> 2, q = e & 3;
             if (e < BN * 4) {
                 // piece q holds channels 8q .. 8q+7: groups 2q and 2q+1 of four; group h is K slot (h & 3, h >> 2)
                 const int h0 = 2 * q, h1 = 2 * q + 1;
-                *reinterpret_cast<uint2*>(s_w[buf] + wswz(row, h0 & 3) + (h0 >> 2) * 8) = make_uint2(wreg[k].x, wreg[k].y);
-                *reinterpret_cast<uint2*>(s_w[buf] + wswz(row, h1 & 3) + (h1 >> 2) * 8) = make_uint2(wreg[k].z, wreg[k].w);
+                *reinterpret_cast<uint2*>(s_w(buf) + wswz(row, h0 & 3) + (h0 >> 2) * 8) = make_uint2(wreg[k].x, wreg[k].y);
+                *reinterpret_cast<uint2*>(s_w(buf) + wswz(row, h1 & 3) + (h1 >> 2) * 8) = make_uint2(wreg[k].z, wreg[k].w);
             }
         }
     };
@@ -152,13 +155,13 @@ __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(P
         uint4 af[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const uint2 lo = read_tr(s_x[buf] + a_off + t * 32);
-            const uint2 hi = read_tr(s_x[buf] + a_off + t * 32 + 16 * kXPitch);
+            const uint2 lo = read_tr(s_x(buf) + a_off + t * 32);
+            const uint2 hi = read_tr(s_x(buf) + a_off + t * 32 + 16 * kXPitch);
             af[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
 #pragma unroll
         for (int j = 0; j < NTL; j++) {
-            const uint4 bf = *reinterpret_cast<const uint4*>(s_w[buf] + wswz(j * 16 + lrow, lgrp));
+            const uint4 bf = *reinterpret_cast<const uint4*>(s_w(buf) + wswz(j * 16 + lrow, lgrp));
 #pragma unroll
             for (int t = 0; t < 4; t++) Mma16<T>::run(af[t], bf, acc[t][j]);
         }
@@ -175,19 +178,41 @@ __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(P
     }
 
     // ---- epilogue: rows 4 lgrp .. 4 lgrp + 3 of tile t are 4 consecutive pixels, the column is the channel ------------
+    // All of a lane's bias values are requested before the first is used, and the addend packets of channel tile j + 1
+    // while tile j is finished (unconditional loads: a packet outside the tensor is read from zeros).  Loaded where they
+    // are used - the bias inside `a.bias ? ... : 0`, an addend packet inside `if (add)` - each was waited for on the
+    // spot: up to 8 + 32 memory round trips in a row at the end of a workgroup whose K loop is a few hundred cycles long.
     T* __restrict__ y = (T*)a.y;
     const T* __restrict__ add = (const T*)a.addend;
     const int64_t px0 = p0 + wave * 64 + lgrp * 4;
+    unsigned short bsr[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; j++) {
         const int ch = co0 + j * 16 + lrow;
-        if (ch >= a.co) continue;
-        const float bs = a.bias ? Elem<T>::load(((const T*)a.bias)[ch]) : 0.f;
+        bsr[j] = load2_or_zero(a.bias != nullptr && ch < a.co, (const T*)a.bias + ch);
+    }
+    uint2 av[2][4];
+    auto load_addend = [&](int j, uint2 (&v)[4]) __attribute__((always_inline)) {
+        if constexpr (ADD) {
+            const int ch = co0 + j * 16 + lrow;
+            const T* src = add + ((int64_t)img * a.co + ch) * a.hw;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t px = px0 + t * 16;
+                v[t] = load8_or_zero(ch < a.co && px < a.hw, src + px);
+            }
+        }
+    };
+    load_addend(0, av[0]);
+#pragma unroll
+    for (int j = 0; j < NTL; j++) {
+        if (j + 1 < NTL) load_addend(j + 1, av[(j + 1) & 1]);
+        const int ch = co0 + j * 16 + lrow;
+        const float bs = unpack_lo<T>(bsr[j]);
         T* dst = y + ((int64_t)img * a.co + ch) * a.hw;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int64_t px = px0 + t * 16;
-            if (px >= a.hw) continue;
             float r[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -195,25 +220,26 @@ __global__ void __launch_bounds__(kThreads, NTL == 8 ? 2 : 3) pointwise_kernel(P
                 z = (z > 0.f) ? z : z * a.slope;
                 r[e] = fminf(fmaxf(z * a.gain, -a.hi), a.hi);
             }
-            if (add) {     // the other branch of a residual block: both summands are rounded values of the tensor's type, the sum is rounded once
-                const uint2 v = *reinterpret_cast<const uint2*>(add + (dst - y) + px);
+            if constexpr (ADD) {     // the other branch of a residual block: both summands are rounded values of the tensor's type, the sum is rounded once
+                const uint2 v = av[j & 1][t];
                 r[0] = Elem<T>::load(Elem<T>::store(r[0])) + unpack_lo<T>(v.x);
                 r[1] = Elem<T>::load(Elem<T>::store(r[1])) + unpack_hi<T>(v.x);
                 r[2] = Elem<T>::load(Elem<T>::store(r[2])) + unpack_lo<T>(v.y);
                 r[3] = Elem<T>::load(Elem<T>::store(r[3])) + unpack_hi<T>(v.y);
             }
-            *reinterpret_cast<uint2*>(dst + px) = make_uint2(pack2<T>(r[0], r[1]), pack2<T>(r[2], r[3]));
+            if (ch < a.co && px < a.hw) *reinterpret_cast<uint2*>(dst + px) = make_uint2(pack2<T>(r[0], r[1]), pack2<T>(r[2], r[3]));
         }
     }
 }
 
 template <class T, int NTL>
 int launch_tiles(const PwArgs& a, hipStream_t stream) {
+    auto kernel = a.addend ? pointwise_kernel<T, NTL, true> : pointwise_kernel<T, NTL, false>;
     const int chunks = a.ci / KCH, nbuf = chunks > 1 ? 2 : 1;
     const size_t lds = (size_t)nbuf * (kXBytes + 16 * NTL * kWRow);
     const int64_t groups = (a.tiles + 7) / 8 * 8 * a.cblocks;
     SG_REQUIRE(groups <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
-    hipLaunchKernelGGL((pointwise_kernel<T, NTL>), dim3((unsigned)groups), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)groups), dim3(kThreads), lds, stream, a);
     return check_launch("sg_conv2d (pointwise)");
 }
 
