@@ -351,9 +351,96 @@ __global__ void __launch_bounds__(256) upfirdn2d_blur4_kernel(sg_upfirdn2d_param
     }
 }
 
+// The same filter on small planes (outputs of 4 x 4 up to 32 x 32: the float32 resolutions of the networks), where
+// the 64 x 32 tile of the kernel above is mostly empty - a 16 x 16 plane uses an eighth of its lanes, a 4 x 4 plane one
+// in 128.  A workgroup takes as many whole planes as give its 256 lanes four outputs of a row each; the planes' input
+// (with the padding as zeros) is staged in LDS as float.
+constexpr int kSmallBlurFloats = 6144;       // LDS image of a workgroup's planes
+__host__ __device__ inline int small_blur_lanes(int out_w, int out_h) { return out_h * ((out_w + 3) / 4); }   // per plane
+inline bool small_blur_eligible(const sg_upfirdn2d_params& p) {
+    if (p.out_w < 4 || p.out_w > 32 || p.out_h < 4 || p.out_h > 32) return false;
+    const int per_wg = 256 / small_blur_lanes(p.out_w, p.out_h);
+    return per_wg >= 1 && (int64_t)per_wg * (p.out_h + 3) * (p.out_w + 3) <= kSmallBlurFloats;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) blur4_small_kernel(sg_upfirdn2d_params p, sg_epilogue ep, bool has_ep) {
+    __shared__ float s_x[kSmallBlurFloats];
+    __shared__ float s_f[16];
+    const T* __restrict__ x = (const T*)p.x;
+    T* __restrict__ y = (T*)p.y;
+    const int tid = threadIdx.x;
+    if (tid < 16) {
+        const int fy = tid / 4, fx = tid % 4;
+        float v = 0;
+        if (fx < p.f_w && fy < p.f_h) {
+            const int sx = p.flip ? fx : p.f_w - 1 - fx, sy = p.flip ? fy : p.f_h - 1 - fy;
+            v = p.f[(int64_t)sx * p.f_stride_w + (int64_t)sy * p.f_stride_h];
+        }
+        s_f[tid] = v * p.gain;
+    }
+    const int iw = p.out_w + 3, ih = p.out_h + 3, img = iw * ih;          // a plane's image: input columns -pad_x0 ..
+    const int groups = (p.out_w + 3) / 4, lanes = p.out_h * groups, per_wg = 256 / lanes;
+    const int planes = p.in_n * p.in_c, plane0 = blockIdx.x * per_wg, here = min(per_wg, planes - plane0);
+    for (int e = tid; e < here * img; e += 256) {
+        const int pl = e / img, r = e - pl * img, ry = r / iw, rx = r - ry * iw;
+        const int plane = plane0 + pl, n = plane / p.in_c, c = plane - n * p.in_c;
+        const int ix = rx - p.pad_x0, iy = ry - p.pad_y0;
+        float v = 0.f;
+        if (ix >= 0 && ix < p.in_w && iy >= 0 && iy < p.in_h)
+            v = (float)Elem<T>::load(x[(int64_t)n * p.in_stride_n + (int64_t)c * p.in_stride_c + (int64_t)iy * p.in_stride_h + ix]);
+        s_x[e] = v;
+    }
+    __syncthreads();
+    const int pl = tid / lanes, l = tid - pl * lanes;
+    if (pl >= here) return;
+    const int oy = l / groups, ox = (l - oy * groups) * 4;
+    const int plane = plane0 + pl, n = plane / p.in_c, c = plane - n * p.in_c;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int fy = 0; fy < 4; fy++) {
+        const float* row = s_x + pl * img + (oy + fy) * iw + ox;
+        float in[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) in[j] = (ox + j < iw) ? row[j] : 0.f;
+#pragma unroll
+        for (int fx = 0; fx < 4; fx++) {
+            const float tap = s_f[fy * 4 + fx];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] += in[j + fx] * tap;
+        }
+    }
+    if (has_ep) {
+        const float sc = ep.scale ? ep.scale[(int64_t)n * p.in_c + c] : 1.f;
+        const float bias = ep.bias ? (float)Elem<T>::load(((const T*)ep.bias)[c]) : 0.f;
+        const float ng = (ep.noise && ep.noise_gain) ? *ep.noise_gain : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v = acc[j] * sc + bias;
+            if (ep.noise && ox + j < p.out_w) v += ep.noise[(int64_t)n * ep.noise_stride_n + (int64_t)oy * p.out_w + ox + j] * ng;
+            if (ep.act == 3) v = (v > 0) ? v : v * ep.alpha;
+            v *= ep.gain;
+            if (ep.clamp >= 0) v = fminf(fmaxf(v, -ep.clamp), ep.clamp);
+            acc[j] = v;
+        }
+    }
+    T* dst = y + (int64_t)n * p.out_stride_n + (int64_t)c * p.out_stride_c + (int64_t)oy * p.out_stride_h + ox;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (ox + j < p.out_w) dst[j] = Elem<T>::store(acc[j]);
+}
+
 template <class T>
 int launch_blur4(const sg_upfirdn2d_params& p, hipStream_t stream, const sg_epilogue* ep = nullptr) {
     if (blur_stream_eligible(p, ep)) return blur_stream_launch(p, ep, stream);
+    if (small_blur_eligible(p)) {
+        const int per_wg = 256 / small_blur_lanes(p.out_w, p.out_h);
+        const int64_t planes = (int64_t)p.in_n * p.in_c;
+        sg_epilogue e = {};
+        if (ep) e = *ep;
+        hipLaunchKernelGGL((blur4_small_kernel<T>), dim3((unsigned)((planes + per_wg - 1) / per_wg)), dim3(256), 0, stream, p, e, ep != nullptr);
+        return check_launch("sg_upfirdn2d (blur, small planes)");
+    }
     const int tiles_x = (p.out_w + 63) / 64, tiles_y = (p.out_h + 31) / 32;
     const int64_t planes = (int64_t)p.in_n * p.in_c, tiles = (int64_t)tiles_x * tiles_y;
     SG_REQUIRE(tiles <= INT32_MAX, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
@@ -461,7 +548,8 @@ extern "C" const char* sg_upfirdn2d_kernel(const sg_upfirdn2d_params* p, const s
     const bool rows_contiguous = p->in_stride_w == 1 && p->out_stride_w == 1;
     const int ux = p->up_x, uy = p->up_y, dx = p->down_x, dy = p->down_y;
     if (rows_contiguous && p->f_w <= 4 && p->f_h <= 4) {
-        if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return blur_stream_eligible(*p, ep) ? "blur4_stream_kernel" : "upfirdn2d_blur4_kernel";
+        if (ux == 1 && uy == 1 && dx == 1 && dy == 1)
+            return blur_stream_eligible(*p, ep) ? "blur4_stream_kernel" : small_blur_eligible(*p) ? "blur4_small_kernel" : "upfirdn2d_blur4_kernel";
         if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return up2_stream_eligible(*p) ? "up2_stream_kernel" : "upfirdn2d_tiled_kernel";
         if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return down2_stream_eligible(*p) ? "down2_stream_kernel" : "upfirdn2d_tiled_kernel";
     }

@@ -187,7 +187,8 @@ int sg_upfirdn2d_epilogue(const sg_upfirdn2d_params* p, const sg_epilogue* ep, s
 
 /* Name of the device kernel sg_upfirdn2d (ep == NULL) or sg_upfirdn2d_epilogue (ep != NULL) runs for this geometry:
  * the symbol a profiler reports, without template arguments ("blur4_stream_kernel", "down2_stream_kernel",
- * "up2_stream_kernel": the streaming kernels for 16-bit planes of whole aligned packets; "upfirdn2d_blur4_kernel",
+ * "up2_stream_kernel": the streaming kernels for 16-bit planes of whole aligned packets; "blur4_small_kernel": the
+ * filter on planes of 4 x 4 to 32 x 32 outputs, several planes per workgroup; "upfirdn2d_blur4_kernel",
  * "upfirdn2d_tiled_kernel", "upfirdn2d_generic_kernel" otherwise).  Static storage.  No counterpart in the
  * reference, whose choice among its kernel specialisations (upfirdn2d.cu:205-341) is not observable. */
 const char* sg_upfirdn2d_kernel(const sg_upfirdn2d_params* p, const sg_epilogue* ep);

@@ -97,6 +97,11 @@ HOT = [  # (name, x shape, up, down, padding, gain): the four instances on the g
     ('stream_up_pad1', [2, 2, 40, 40], 2, 1, [1, 2, 3, 0], 4.0),
     ('stream_up_pad03', [2, 2, 33, 48], 2, 1, [0, 3, 0, 1], 1.0),
     ('stream_up_pad3', [2, 2, 33, 48], 2, 1, [3, 0, 2, 1], 1.0),
+    # planes of 4 x 4 to 32 x 32 outputs: several planes per workgroup
+    ('small_blur_16', [5, 7, 17, 24], 1, 1, [1, -6, 1, 1], 4.0),               # the filter behind a 8 -> 16 up-sampling layer
+    ('small_blur_4', [3, 70, 5, 8], 1, 1, [1, -2, 1, 1], 4.0),                 # 64 planes per workgroup, a last partial one
+    ('small_blur_odd', [2, 9, 11, 30], 1, 1, [2, 1, 0, 3], 1.0),               # 11 x 30 outputs
+    ('small_blur_32', [2, 3, 33, 33], 1, 1, [1, 1, 1, 1], 1.0),                # one plane per workgroup
 ]
 
 
