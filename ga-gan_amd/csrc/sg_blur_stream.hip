@@ -366,7 +366,9 @@ int launch_down2_pad(const sg_upfirdn2d_params& p, hipStream_t stream) {
 // row r completes the output rows e = 2r - 3, 2r - 2 (its filter rows 3 and 2 on top of what row r - 1 left) and
 // starts the rows 2r - 1, 2r (filter rows 1 and 0), with e = output row - pad_y0.  No rotation, 2 packed
 // multiply-adds per output.
-template <class T, int PADX>
+struct AddendRows { uint4 v[2][2][2]; };     // [output row of the pair an input row completes][plane][half of the lane's 16 columns]
+
+template <class T, int PADX, bool ADD>
 __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, const void* addend, int lpr, int cblocks, int bands, int units) {
     constexpr int kColsUp = 1024;                 // 16 output columns per lane
     const int lane = threadIdx.x & 63;
@@ -383,8 +385,11 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
     T* __restrict__ y0 = (T*)p.y + (int64_t)n0 * p.out_stride_n + (int64_t)c0 * p.out_stride_c;
     T* __restrict__ y1 = (T*)p.y + (int64_t)n1 * p.out_stride_n + (int64_t)c1 * p.out_stride_c;
     // optional addend with the output's strides: y = round(round(filtered) + addend), the arithmetic of a separate add
-    const T* __restrict__ a0 = addend ? (const T*)addend + (int64_t)n0 * p.out_stride_n + (int64_t)c0 * p.out_stride_c : nullptr;
-    const T* __restrict__ a1 = addend ? (const T*)addend + (int64_t)n1 * p.out_stride_n + (int64_t)c1 * p.out_stride_c : nullptr;
+    // (ADD: its packets are requested one input row ahead of the output rows they are added to, unconditionally - read
+    // where they were used, inside `if (addend)`, each was waited for on the spot together with the rows in flight:
+    // 64 x 64 planes of 128^2 -> 256^2 took 0.49 ms with an addend and 0.19 without)
+    const T* __restrict__ a0 = ADD ? (const T*)addend + (int64_t)n0 * p.out_stride_n + (int64_t)c0 * p.out_stride_c : nullptr;
+    const T* __restrict__ a1 = ADD ? (const T*)addend + (int64_t)n1 * p.out_stride_n + (int64_t)c1 * p.out_stride_c : nullptr;
     const int ox0 = cb * kColsUp + (lane - sub * lpr) * 16, oy0 = bd * kBand;
     const int rows = live ? min(kBand, p.out_h - oy0) : 0;
     const bool col_ok = live && ox0 < p.out_w;
@@ -424,12 +429,26 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
 #pragma unroll
     for (int j = 0; j < 32; j++) pend[j >> 4][j & 15] = f32x2_t{0.f, 0.f};
 
-    auto store_row = [&](int e, const f32x2_t (&v)[16]) __attribute__((always_inline)) {
+    auto load_addend = [&](int k, AddendRows& dst) __attribute__((always_inline)) {   // for the rows input row k completes
+        if constexpr (ADD) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int oy = 2 * (r_first + k) - 3 + rr + p.pad_y0;
+                const bool ok = oy >= oy0 && oy < oy0 + rows && col_ok;
+                const int64_t off = (int64_t)oy * p.out_stride_h + ox0;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    dst.v[rr][0][h] = load16_or_zero(ok, a0 + off + 8 * h);
+                    dst.v[rr][1][h] = load16_or_zero(ok && second, a1 + off + 8 * h);
+                }
+            }
+        }
+    };
+    auto store_row = [&](int e, const f32x2_t (&v)[16], const uint4 (&av)[2][2]) __attribute__((always_inline)) {
         const int oy = e + p.pad_y0;
         if (oy < oy0 || oy >= oy0 + rows || !col_ok) return;
         const int64_t off = (int64_t)oy * p.out_stride_h + ox0;
-        auto plus = [&](const uint4& r, const T* a) __attribute__((always_inline)) {   // packed results + 8 addend elements
-            const uint4 q = *reinterpret_cast<const uint4*>(a);
+        auto plus = [&](const uint4& r, const uint4& q) __attribute__((always_inline)) {   // packed results + 8 addend elements
             const unsigned rw[4] = {r.x, r.y, r.z, r.w}, qw[4] = {q.x, q.y, q.z, q.w};
             unsigned o[4];
 #pragma unroll
@@ -441,17 +460,17 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
         for (int h = 0; h < 2; h++) {
             uint4 r0 = make_uint4(Pair<T>::pack(v[8 * h][0], v[8 * h + 1][0]), Pair<T>::pack(v[8 * h + 2][0], v[8 * h + 3][0]),
                                   Pair<T>::pack(v[8 * h + 4][0], v[8 * h + 5][0]), Pair<T>::pack(v[8 * h + 6][0], v[8 * h + 7][0]));
-            if (a0) r0 = plus(r0, a0 + off + 8 * h);
+            if constexpr (ADD) r0 = plus(r0, av[0][h]);
             *reinterpret_cast<uint4*>(y0 + off + 8 * h) = r0;
             if (second) {
                 uint4 r1 = make_uint4(Pair<T>::pack(v[8 * h][1], v[8 * h + 1][1]), Pair<T>::pack(v[8 * h + 2][1], v[8 * h + 3][1]),
                                       Pair<T>::pack(v[8 * h + 4][1], v[8 * h + 5][1]), Pair<T>::pack(v[8 * h + 6][1], v[8 * h + 7][1]));
-                if (a1) r1 = plus(r1, a1 + off + 8 * h);
+                if constexpr (ADD) r1 = plus(r1, av[1][h]);
                 *reinterpret_cast<uint4*>(y1 + off + 8 * h) = r1;
             }
         }
     };
-    auto consume = [&](int k, const Row& row) __attribute__((always_inline)) {
+    auto consume = [&](int k, const Row& row, const AddendRows& ar) __attribute__((always_inline)) {
         f32x2_t in[16];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -485,24 +504,27 @@ __global__ void __launch_bounds__(256) up2_stream_kernel(sg_upfirdn2d_params p, 
         };
         const int r = r_first + k;
         hrow(3, pend[1], true);
-        store_row(2 * r - 3, pend[1]);
+        store_row(2 * r - 3, pend[1], ar.v[0]);
         hrow(2, pend[0], true);
-        store_row(2 * r - 2, pend[0]);
+        store_row(2 * r - 2, pend[0], ar.v[1]);
         hrow(1, pend[1], false);
         hrow(0, pend[0], false);
     };
 
     Row ra, rb;
+    AddendRows aa, ab;
     load_row(0, ra);
     load_row(1, rb);
+    load_addend(0, aa);
     const int total = min(kBand, p.out_h) / 2 + 3;
     for (int k0 = 0; k0 < total; k0 += 2) {
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const int k = k0 + s;
             Row cur = s ? rb : ra;
+            load_addend(k + 1, s ? aa : ab);
             load_row(k + 2, s ? rb : ra);
-            consume(k, cur);
+            consume(k, cur, s ? ab : aa);
         }
     }
 }
@@ -515,7 +537,8 @@ int launch_up2(const sg_upfirdn2d_params& p, const void* addend, hipStream_t str
     const int64_t units = pairs * cblocks * bands;
     SG_REQUIRE(units <= INT32_MAX / 2, SG_ERR_INVALID_ARGUMENT, "output has too many tiles");
     const int64_t waves = (units + 64 / lpr - 1) / (64 / lpr);
-    hipLaunchKernelGGL((up2_stream_kernel<T, PADX>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p, addend, lpr, cblocks, bands, (int)units);
+    auto kernel = addend ? up2_stream_kernel<T, PADX, true> : up2_stream_kernel<T, PADX, false>;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p, addend, lpr, cblocks, bands, (int)units);
     return check_launch("sg_upfirdn2d (up-sampling stream)");
 }
 
