@@ -212,13 +212,18 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
             return r;
         };
         if constexpr (CO_R > 0) {
+            // the reduction packets of the next four channels are requested before this group's arithmetic and stores
+            uint4 rxv[2][4];
 #pragma unroll
-            for (int o0 = 0; o0 < CO_R; o0 += 4) {     // 4 reduction packets in flight
-                uint4 rxv[4];
+            for (int u = 0; u < 4; u++) rxv[0][u] = *reinterpret_cast<const uint4*>(rn + u * plane + (int64_t)pk * 8);
 #pragma unroll
-                for (int u = 0; u < 4; u++) rxv[u] = *reinterpret_cast<const uint4*>(rn + (o0 + u) * plane + (int64_t)pk * 8);
+            for (int o0 = 0; o0 < CO_R; o0 += 4) {
+                if (o0 + 4 < CO_R) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) red[o0 + u] += one(o0 + u, rxv[u]);
+                    for (int u = 0; u < 4; u++) rxv[((o0 >> 2) + 1) & 1][u] = *reinterpret_cast<const uint4*>(rn + (o0 + 4 + u) * plane + (int64_t)pk * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) red[o0 + u] += one(o0 + u, rxv[(o0 >> 2) & 1][u]);
             }
         } else {
             for (int o = 0; o < g.co; o++) one(o, make_uint4(0, 0, 0, 0));
@@ -290,23 +295,14 @@ __global__ void __launch_bounds__(256) wgrad1x1_few_kernel(FewWgradArgs g) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int row = 4 * k + srow;
-            va[k] = make_uint4(0, 0, 0, 0);
-            if constexpr (MASK) vm[k] = make_uint4(0, 0, 0, 0);
-            if (p_ok && row < rows_m) {
-                va[k] = *reinterpret_cast<const uint4*>(pm + row * plane + (int64_t)p * 8);
-                if constexpr (MASK) {
-                    if (pmask_m) vm[k] = *reinterpret_cast<const uint4*>(pmask_m + row * plane + (int64_t)p * 8);
-                }
-            }
+            const bool ok = p_ok && row < rows_m;             // (unconditional loads: a packet outside is read from zeros)
+            va[k] = load16_or_zero(ok, pm + row * plane + (int64_t)p * 8);
+            if constexpr (MASK) vm[k] = load16_or_zero(ok && pmask_m != nullptr, pmask_m + row * plane + (int64_t)p * 8);
         }
-        vf = make_uint4(0, 0, 0, 0);
+        const bool f_row = p_ok && srow < g.cf;
+        vf = load16_or_zero(f_row, pf + srow * plane + (int64_t)p * 8);
         vfm = make_uint4(0, 0, 0, 0);
-        if (p_ok && srow < g.cf) {
-            vf = *reinterpret_cast<const uint4*>(pf + srow * plane + (int64_t)p * 8);
-            if constexpr (MASK) {
-                if (pmask_f) vfm = *reinterpret_cast<const uint4*>(pmask_f + srow * plane + (int64_t)p * 8);
-            }
-        }
+        if constexpr (MASK) vfm = load16_or_zero(f_row && pmask_f != nullptr, pmask_f + srow * plane + (int64_t)p * 8);
     };
     auto park = [&]() __attribute__((always_inline)) {
 #pragma unroll
