@@ -732,7 +732,9 @@ bool conv3x3_eligible(const sg_conv2d_params& p) {
     if (p.num_phases != 1 || p.in_step < 1 || p.in_step > 2 || p.out_step != 1) return false;
     const sg_conv2d_phase& ph = p.phase[0];
     if (ph.nky != 3 || ph.nkx != 3 || ph.oy0 != 0 || ph.ox0 != 0 || ph.w_offset != 0) return false;
-    if (p.ow < TW || p.oh < 5) return false;                      // smaller outputs would leave most of the 8 x 32 tile empty
+    // smaller outputs would leave most of the 8 x 32 tile empty (half of it is accepted at stride 2: the strided 512 -> 512
+    // layer at 32^2 -> 16^2 runs 1.6x the rate of the general kernel with every second column of its tiles idle)
+    if (p.ow < (p.in_step == 2 ? TW / 2 : TW) || p.oh < 5) return false;
     if (p.act == 3 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;   // the epilogue takes the leaky ReLU as a max
     if (p.w_in % 8 != 0 || p.ow % 4 != 0 || p.ci % 8 != 0) return false;
     if ((int64_t)p.ci * p.h * p.w_in >= (int64_t)1 << 30) return false;   // a sample's bytes bound the buffer offsets (< 2^31)

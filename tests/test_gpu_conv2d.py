@@ -47,6 +47,8 @@ CASES = [  # name, n, ci, co, h, w, k, kind, stride, padding
     ('3x3_stride2_fast3', 2, 96, 64, 67, 136, 3, 'conv', 2, 1),    # 34 x 68 outputs: eligible, ragged tiles
     ('3x3_stride2_resident', 2, 32, 64, 41, 72, 3, 'conv', 2, 1),  # one chunk, up to 64 outputs: weights stay in LDS, tiles stream
     ('3x3_stride2_resident48', 3, 32, 48, 67, 136, 3, 'conv', 2, 1),
+    ('3x3_stride2_half', 3, 96, 136, 33, 40, 3, 'conv', 2, 1),       # 17 x 20 outputs: tiles of 32 columns half empty
+    ('3x3_stride2_half_resident', 2, 32, 64, 33, 40, 3, 'conv', 2, 1),
     ('3x3_nopad', 2, 32, 32, 18, 18, 3, 'conv', 1, 0),
     ('t3x3_up2', 2, 64, 32, 16, 16, 3, 'conv_transpose', 2, 0),
     ('t3x3_up2_pad1', 2, 32, 32, 9, 13, 3, 'conv_transpose', 2, 1),
