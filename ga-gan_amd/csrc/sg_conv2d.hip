@@ -1162,6 +1162,7 @@ extern "C" int sg_conv2d_wgrad(const sg_conv2d_wgrad_params* p, sg_stream_t stre
     if (wgrad_rows_eligible(*p)) return wgrad_rows_launch(*p, (hipStream_t)stream);
     SG_REQUIRE(p->mask_y == nullptr, SG_ERR_UNSUPPORTED, "conv2d_wgrad: no kernel applies a gradient mask for this geometry");
     if (wgrad3x3_eligible(*p)) return wgrad3x3_launch(*p, (hipStream_t)stream);
+    if (wgrad1x1_eligible(*p)) return wgrad1x1_launch(*p, (hipStream_t)stream);
     if (wgrad_f32_eligible(*p)) return wgrad_f32_launch(*p, (hipStream_t)stream);
     switch (p->dtype) {
         case SG_F32: return launch_wgrad<float>(*p, (hipStream_t)stream);
@@ -1254,6 +1255,7 @@ extern "C" const char* sg_conv2d_wgrad_kernel(const sg_conv2d_wgrad_params* p) {
     if (sg::wgrad1x1_few_eligible(*p)) return "wgrad1x1_few_kernel";
     if (sg::wgrad_rows_eligible(*p)) return "wgrad_rows_kernel";
     if (sg::wgrad3x3_eligible(*p)) return "wgrad3x3_kernel";
+    if (sg::wgrad1x1_eligible(*p)) return "wgrad1x1_kernel";
     return sg::wgrad_f32_eligible(*p) ? "wgrad_f32_kernel" : "conv2d_wgrad_kernel";
 }
 

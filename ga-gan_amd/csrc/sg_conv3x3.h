@@ -53,6 +53,8 @@ bool wgrad3x3_eligible(const sg_conv2d_wgrad_params& p);
 int wgrad3x3_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
 
 // Weight gradient of same-size 3x3 layers with 32 channels on both sides, with the activation mask (sg_wgrad_rows.hip).
+bool wgrad1x1_eligible(const sg_conv2d_wgrad_params& p);    // 16-bit 1x1 layers with 32 or more channels on both sides
+int wgrad1x1_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
 bool wgrad_rows_eligible(const sg_conv2d_wgrad_params& p);
 int wgrad_rows_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream);
 

@@ -20,6 +20,8 @@
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
+#include <algorithm>
+
 namespace sg {
 namespace {
 
@@ -260,6 +262,101 @@ int launch_pointwise(const sg_conv2d_params& p, hipStream_t stream) {
     return launch_tiles<T, 8>(a, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of those layers: dw[cg][cx] += sum over samples and pixels of g[n, cg, p] x[n, cx, p].  Both operands
+// lie in memory as [channel][pixel], which is the K-contiguous row order the matrix instruction wants of both of its
+// operands: a chunk of 128 pixels goes to LDS as it is (16-byte copies, rows of 272 bytes: the 16 rows a ds_read_b128
+// lane group touches fall on 16 different bank slots) and every fragment is one 16-byte read - no transposition at
+// all.  A workgroup owns a block of 128 x 64 weights (the general kernel's 32 x 32 blocks read g twice and x four
+// times for 64 -> 128 channels: 2.7 times the bytes of the tensors; here each is read once per block column / row),
+// its four waves 64 x 32 each; the pixels are divided over blockIdx.x and the partial blocks meet in dw by float
+// atomics.  The next chunk's packets are requested before the multiplies of the current one.
+constexpr int kWgPx = 128;                       // pixels per chunk
+constexpr int kWgBG = 128, kWgBX = 64;           // block of dw: gradient channels x input channels
+constexpr int kWgRowBytes = kWgPx * 2 + 16;      // 272
+constexpr int kWgIt = (kWgBG + kWgBX) * (kWgPx / 8) / kThreads;   // 16-byte packets per lane and chunk: 12
+
+struct Wg1x1Args {
+    const void* g; const void* x; float* dw;
+    int n, cg, cx;
+    int64_t hw;
+    int chunks_img;      // pixel chunks per image
+    int64_t chunks;      // in all
+    int per_wg;          // chunks per workgroup (blockIdx.x)
+};
+
+template <class T>
+__global__ void __launch_bounds__(kThreads, 2) wgrad1x1_kernel(Wg1x1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [128 + 64 rows][272 bytes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int g0 = blockIdx.y * kWgBG, x0 = blockIdx.z * kWgBX;
+    const T* __restrict__ g = (const T*)a.g;
+    const T* __restrict__ x = (const T*)a.x;
+
+    // staging: packet e = tid + 256 k is 16-byte piece e & 15 of row e >> 4 (rows 0 .. 127: g, 128 .. 191: x)
+    uint4 v[kWgIt];
+    auto load = [&](int64_t chunk) __attribute__((always_inline)) {
+        const int img = (int)(chunk / a.chunks_img);
+        const int64_t p0 = (chunk - (int64_t)img * a.chunks_img) * kWgPx;
+#pragma unroll
+        for (int k = 0; k < kWgIt; k++) {
+            const int e = tid + k * kThreads, row = e >> 4, pk = e & 15;
+            const bool is_g = row < kWgBG;
+            const int ch = is_g ? g0 + row : x0 + row - kWgBG;
+            const bool ok = p0 + pk * 8 < a.hw && (is_g ? ch < a.cg : ch < a.cx);
+            const T* src = is_g ? g + ((int64_t)img * a.cg + ch) * a.hw : x + ((int64_t)img * a.cx + ch) * a.hw;
+            v[k] = load16_or_zero(ok, src + p0 + pk * 8);
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < kWgIt; k++) {
+            const int e = tid + k * kThreads;
+            *reinterpret_cast<uint4*>(smem + (e >> 4) * kWgRowBytes + (e & 15) * 16) = v[k];
+        }
+    };
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* a_src = smem + ((wave >> 1) * 64 + lrow) * kWgRowBytes + lgrp * 16;
+    const unsigned char* b_src = smem + (kWgBG + (wave & 1) * 32 + lrow) * kWgRowBytes + lgrp * 16;
+
+    const int64_t c0 = (int64_t)blockIdx.x * a.per_wg, c1 = min(a.chunks, c0 + a.per_wg);
+    if (c0 >= c1) return;
+    load(c0);
+    for (int64_t c = c0; c < c1; c++) {
+        __syncthreads();          // the previous chunk's reads are done
+        commit();
+        __syncthreads();
+        if (c + 1 < c1) load(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < kWgPx / 32; ks++) {
+            uint4 fa[4], fb[2];
+#pragma unroll
+            for (int m = 0; m < 4; m++) fa[m] = *reinterpret_cast<const uint4*>(a_src + m * 16 * kWgRowBytes + ks * 64);
+#pragma unroll
+            for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const uint4*>(b_src + j * 16 * kWgRowBytes + ks * 64);
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) Mma16<T>::run(fa[m], fb[j], acc[m][j]);     // rows: g channels, columns: x channels
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int cg = g0 + (wave >> 1) * 64 + m * 16 + lgrp * 4 + r, cx = x0 + (wave & 1) * 32 + j * 16 + lrow;
+                if (cg < a.cg && cx < a.cx) atomicAdd(a.dw + (int64_t)cg * a.cx + cx, acc[m][j][r]);
+            }
+}
+
 }  // namespace
 
 bool pointwise_eligible(const sg_conv2d_params& p) {
@@ -277,6 +374,35 @@ bool pointwise_eligible(const sg_conv2d_params& p) {
 
 int pointwise_launch(const sg_conv2d_params& p, hipStream_t stream) {
     return (p.dtype == SG_BF16) ? launch_pointwise<__hip_bfloat16>(p, stream) : launch_pointwise<__half>(p, stream);
+}
+
+bool wgrad1x1_eligible(const sg_conv2d_wgrad_params& p) {
+    if (p.dtype != SG_F16 && p.dtype != SG_BF16) return false;
+    if (p.nky != 1 || p.nkx != 1 || p.step != 1 || p.dy0 != 0 || p.dx0 != 0 || p.gh != p.h || p.gw != p.w_in) return false;
+    if (p.x_scale || p.g_scale || p.mask_y) return false;
+    if (p.cx < 32 || p.cg < 32) return false;
+    const int64_t hw = (int64_t)p.h * p.w_in;
+    if (hw % 8 != 0 || hw * p.n < 16 * kWgPx) return false;
+    return aligned16(p.x) && aligned16(p.g);
+}
+
+int wgrad1x1_launch(const sg_conv2d_wgrad_params& p, hipStream_t stream) {
+    Wg1x1Args a;
+    a.g = p.g; a.x = p.x; a.dw = p.dw;
+    a.n = p.n; a.cg = p.cg; a.cx = p.cx;
+    a.hw = (int64_t)p.h * p.w_in;
+    a.chunks_img = (int)((a.hw + kWgPx - 1) / kWgPx);
+    a.chunks = (int64_t)a.chunks_img * p.n;
+    const int blocks = ((p.cg + kWgBG - 1) / kWgBG) * ((p.cx + kWgBX - 1) / kWgBX);
+    // about four workgroups per CU, and at least eight chunks each: every workgroup ends in 8,192 atomic adds
+    int64_t split = std::max<int64_t>(1, std::min<int64_t>((1024 + blocks - 1) / blocks, a.chunks / 8));
+    a.per_wg = (int)((a.chunks + split - 1) / split);
+    split = (a.chunks + a.per_wg - 1) / a.per_wg;
+    const dim3 grid((unsigned)split, (unsigned)((p.cg + kWgBG - 1) / kWgBG), (unsigned)((p.cx + kWgBX - 1) / kWgBX));
+    const size_t lds = (size_t)(kWgBG + kWgBX) * kWgRowBytes;
+    if (p.dtype == SG_BF16) hipLaunchKernelGGL((wgrad1x1_kernel<__hip_bfloat16>), grid, dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL((wgrad1x1_kernel<__half>), grid, dim3(kThreads), lds, stream, a);
+    return check_launch("sg_conv2d_wgrad (1x1)");
 }
 
 }  // namespace sg

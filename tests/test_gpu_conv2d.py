@@ -252,6 +252,10 @@ WGRAD_CASES = [  # name, n, ci, co, h, w, k, stride, padding
     ('3x3_stride2_g16', 5, 64, 96, 40, 40, 3, 2, 0),            # gradient planes 19 x 19 / 16 columns wide: half-filled tiles
     ('3x3_stride2_g16b', 4, 64, 64, 33, 40, 3, 2, 0),
     ('3x3_g16', 3, 64, 64, 12, 16, 3, 1, 1),
+    # 16-bit 1x1 layers with 32 or more channels on both sides: blocks of 128 x 64 weights
+    ('1x1_skip', 3, 64, 128, 32, 32, 1, 1, 0),
+    ('1x1_skip_ragged', 2, 72, 200, 36, 40, 1, 1, 0),           # partly filled blocks, a last chunk of 32 pixels
+    ('1x1_skip_wide', 2, 256, 136, 16, 24, 1, 1, 0),            # four block columns, two block rows
 ]
 
 
