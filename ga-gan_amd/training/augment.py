@@ -26,6 +26,7 @@ lives on the device, as the reference's buffer does; its value is read back when
 import numpy as np
 import torch
 
+from ..torch_utils import persistence
 from ..torch_utils.ops import conv2d_gradfix
 from ..torch_utils.ops import grid_sample_gradfix
 from ..torch_utils.ops import upfirdn2d
@@ -98,6 +99,7 @@ def _filter_bank():
     return bank
 
 
+@persistence.records_init
 class AugmentPipe(torch.nn.Module):
     def __init__(self, xflip=0, rotate90=0, xint=0, xint_max=0.125,
                  scale=0, rotate=0, aniso=0, xfrac=0, scale_std=0.2, rotate_max=1, aniso_std=0.2, xfrac_std=0.125,

@@ -25,6 +25,7 @@ import torch
 
 from ..torch_utils import memo
 from ..torch_utils import misc
+from ..torch_utils import persistence
 from ..torch_utils.ops import bias_act
 from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import fma
@@ -450,6 +451,7 @@ def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding
 
 # ----------------------------------------------------------------------------
 
+@persistence.records_init
 class FullyConnectedLayer(torch.nn.Module):
     def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
         super().__init__()
@@ -471,6 +473,7 @@ class FullyConnectedLayer(torch.nn.Module):
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
 
+@persistence.records_init
 class Conv2dLayer(torch.nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
                  resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True):
@@ -542,6 +545,7 @@ def _conv2d_layer_with_residual(self, x, gain, residual):
 Conv2dLayer._with_residual = _conv2d_layer_with_residual
 
 
+@persistence.records_init
 class MappingNetwork(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
                  activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995):
@@ -592,6 +596,7 @@ class MappingNetwork(torch.nn.Module):
         return x
 
 
+@persistence.records_init
 class SynthesisLayer(torch.nn.Module):
     def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True,
                  activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False,
@@ -648,6 +653,7 @@ class SynthesisLayer(torch.nn.Module):
         return bias_act.bias_act(x, bias, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
 
 
+@persistence.records_init
 class ToRGBLayer(torch.nn.Module):
     def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=1, conv_clamp=None,
                  channels_last=False, use_domain_modulation=False, domain_modulation_parametrization='multiplicative',
@@ -694,6 +700,7 @@ def _block_precision(block, force_fp32):
             torch.channels_last if block.channels_last and not force_fp32 else torch.contiguous_format)
 
 
+@persistence.records_init
 class SynthesisBlock(torch.nn.Module):
     """One resolution of the generator: [const | conv0 (up 2)] -> conv1 -> to-RGB added to the up-sampled image.
     Sub-module and parameter names are the reference's (training/networks.py:968-1026); the forward pass is the
@@ -763,6 +770,7 @@ class SynthesisBlock(torch.nn.Module):
         return x, img
 
 
+@persistence.records_init
 class SynthesisNetwork(torch.nn.Module):
     """Blocks b4 .. b<img_resolution>; row k of `ws` feeds the k-th convolution in order, and a block's to-RGB
     layer shares the row of the next block's first convolution (reference: training/networks.py:1079-1132)."""
@@ -801,6 +809,7 @@ class SynthesisNetwork(torch.nn.Module):
         return img
 
 
+@persistence.records_init
 class Generator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
         super().__init__()
@@ -825,6 +834,7 @@ class Generator(torch.nn.Module):
 
 # ----------------------------------------------------------------------------
 
+@persistence.records_init
 class DiscriminatorBlock(torch.nn.Module):
     """One resolution of the discriminator: [from-RGB] -> conv0 -> conv1 (down 2), with a 1x1 down-sampling shortcut in
     the 'resnet' architecture.  Names and layer numbering (Freeze-D) follow training/networks.py:1176-1242."""
@@ -876,6 +886,7 @@ class DiscriminatorBlock(torch.nn.Module):
         return x, img
 
 
+@persistence.records_init
 class MinibatchStdLayer(torch.nn.Module):
     def __init__(self, group_size, num_channels=1):
         super().__init__()
@@ -886,6 +897,7 @@ class MinibatchStdLayer(torch.nn.Module):
         return minibatch_std.minibatch_std(x, self.group_size, self.num_channels)
 
 
+@persistence.records_init
 class DiscriminatorEpilogue(torch.nn.Module):
     def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4,
                  mbstd_num_channels=1, activation='lrelu', conv_clamp=None, **_):
@@ -923,6 +935,7 @@ class DiscriminatorEpilogue(torch.nn.Module):
         return x
 
 
+@persistence.records_init
 class Discriminator(torch.nn.Module):
     """Blocks b<img_resolution> .. b8, then the 4 x 4 epilogue b4 (reference: training/networks.py:1372-1437)."""
 

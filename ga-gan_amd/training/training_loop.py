@@ -455,6 +455,19 @@ class Trainer:
     def save(self, path):
         torch.save(self.snapshot(), path)
 
+    def save_network_pkl(self, path, training_set_kwargs=None):
+        """The reference's `network-snapshot-*.pkl` (training_loop.py:586-601): G, D, G_ema and the augmentation pipe as
+        evaluation-mode copies without gradients on the CPU, in the record layout its `legacy.load_network_pkl` and
+        this package's read."""
+        from .. import legacy
+        data = dict(training_set_kwargs=dict(training_set_kwargs or {}))
+        for name, module in (('G', self.G), ('D', self.D), ('G_ema', self.G_ema), ('augment_pipe', self.augment_pipe)):
+            if module is not None:
+                module = copy.deepcopy(module).eval().requires_grad_(False).cpu()
+            data[name] = module
+        with open(path, 'wb') as f:
+            legacy.save_network_pkl(f, data)
+
     def load(self, path):
         """Tensors, numbers and containers only: read with `weights_only=True` (nothing in the file is executed)."""
         self.load_snapshot(torch.load(path, map_location=self.device, weights_only=True))

@@ -594,6 +594,14 @@ def test_trainer_snapshot_round_trip(tmp_path):
         a.step(*batches[i], gen_z=zs[i])
     path = str(tmp_path / 'snapshot.pt')
     a.save(path)
+    from ga_gan_amd import legacy
+    a.save_network_pkl(str(tmp_path / 'network-snapshot.pkl'), training_set_kwargs=dict(path='x.zip'))
+    with open(tmp_path / 'network-snapshot.pkl', 'rb') as f:         # the reference's snapshot format, read back
+        nets = legacy.load_network_pkl(f)
+    assert nets['training_set_kwargs'] == dict(path='x.zip') and nets['augment_pipe'] is None
+    for name in ('G', 'D', 'G_ema'):
+        for (n, p), (n2, q) in zip(getattr(a, name).state_dict().items(), nets[name].state_dict().items()):
+            assert n == n2 and q.device.type == 'cpu' and torch.equal(p.cpu(), q), (name, n)
     b = training_loop.Trainer(**kwargs)
     b.loss.synthesis_kwargs = dict(noise_mode='const')
     b.load(path)
@@ -722,3 +730,29 @@ def test_full_size_discriminator_bf16_against_rounded_oracle(case):
     assert logit_err < 1e-2
     assert image_err < 4e-2
     assert worst_param[0] < 2.5e-2, errs[:4]
+
+
+def test_networks_read_from_a_reference_snapshot_reproduce_its_outputs():
+    """`tests/golden/snapshot_ref.pkl` was pickled by the reference (tools/gen_golden_snapshots.py); the networks
+    `legacy.load_network_pkl` builds from it give the mapping outputs, images and logits the reference computed with
+    the objects it pickled."""
+    import json
+    import os
+    import numpy as np
+    from ga_gan_amd import legacy
+    with open(os.path.join(golden_io.GOLDEN, 'snapshot_ref.pkl'), 'rb') as f:
+        nets = legacy.load_network_pkl(f)
+    with np.load(os.path.join(golden_io.GOLDEN, 'snapshot_ref.npz')) as zf:
+        want = {k: torch.from_numpy(zf[k]) for k in zf.files if k != 'meta'}
+    z = want['z'].to(DEV)
+    c = torch.zeros(z.shape[0], 0, device=DEV)
+    with torch.no_grad():
+        for name in ('G', 'G_ema'):
+            G = nets[name].to(DEV)
+            close(G.mapping(z, c), want[name + '.ws'], 1e-5, name + '.ws')
+            close(G.mapping(z, c, truncation_psi=0.5, truncation_cutoff=4), want[name + '.ws_truncated'], 1e-5, name + '.ws_truncated')
+            img = G(z, c, noise_mode='const')
+            close(img, want[name + '.img'], 1e-4, name + '.img')
+            assert golden_io.rel_err(img, want[name + '.img']) < 1e-3
+        img = want['img'].to(DEV)
+        close(nets['D'].to(DEV)(img, torch.zeros(img.shape[0], 0, device=DEV)), want['D.logits'], 1e-4, 'D.logits')
