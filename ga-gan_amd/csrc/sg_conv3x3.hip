@@ -50,7 +50,7 @@ template <int STEP> struct Geo {
     static constexpr int ITEMS = LH * NV;                          // (row, packet) items per channel pair
     static constexpr int STEPS = (ITEMS + 15) / 16;                // items per lane: 4 / 10
     static constexpr int kInPadded = STEPS * 16 * 8 * kRow;        // the image with room for all 16 STEPS item slots: 32768 / 81920
-    static constexpr int BLOCKS_PER_CU = (kInBytes + kWBytes) * 2 <= 160 * 1024 ? 2 : 1;
+    static constexpr int BLOCKS_PER_CU = (kInPadded + kWBytes) * 2 <= 160 * 1024 ? 2 : 1;
 };
 
 template <class T> struct Mma16;
@@ -158,63 +158,104 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
 // and where their eight pixels go in the LDS image.  A chunk then costs a handful of scalar instructions (the
 // descriptors move on by one chunk of channels), one load instruction per packet and, per pair of elements, two
 // multiplies and one conversion (or one byte permute without modulation).
+constexpr bool conv3x3_persistent(int step, int waves) {
+    return (Geo<1>::ITEMS * (step == 1) + Geo<2>::ITEMS * (step == 2) + 4 * waves - 1) / (4 * waves) <= 2;    // items per lane
+}
+
 template <class T, int STEP, int WAVES, bool MOD, int ADJ>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS_PER_CU) conv3x3_kernel(Conv3x3Args g) {
     using G = Geo<STEP>;
     constexpr int NV = G::NV, LWP = G::LWP;
     constexpr int THREADS = 64 * WAVES, BMT = BM * (WAVES / 4);   // lanes and output channels per workgroup
     constexpr int SLOTS = THREADS / 16, STEPS = (G::ITEMS + SLOTS - 1) / SLOTS;   // staging: item slots, items per lane
-    constexpr bool LAST_PARTIAL = (G::ITEMS % SLOTS) != 0;        // the last item exists for the first slots only
+    static_assert(SLOTS * STEPS * 8 * kRow <= G::kInPadded, "the padded image holds every item slot");
+    // Persistent where the registers hold the next tile's first chunk beside the current tile's epilogue (two items per
+    // lane: the 8-wave form at unit stride, which carries nearly all of this kernel's work); the other forms, launched
+    // with one workgroup per tile, leave the loop after their tile (as a loop they spill 14-52 registers per lane).
+    constexpr bool PERSISTENT = conv3x3_persistent(STEP, WAVES);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_in = smem;
-    unsigned char* s_w = smem + G::kInBytes;
+    unsigned char* s_w = smem + G::kInPadded;
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = (tid >> 6) & 3, half = tid >> 8;   // pixel rows 2 wave, 2 wave + 1 of the tile; channels 64 half ..
-    const int lrow = lane & 15, lgrp = lane >> 4;
+    // What a lane derives from its index alone (its rows of the tile, its staging items, its LDS addresses) is derived
+    // again at the head of every tile from an index the compiler cannot see through (lane_constants): kept across the
+    // tile loop instead, those forty-odd values are live through the multiply phases of every chunk and the kernel
+    // spills (42-128 registers per lane against none).
+    int tid = threadIdx.x;
+    int wave, half, lrow, lgrp;   // pixel rows 2 wave, 2 wave + 1 of the tile; channels 64 half ..; lane = (lrow, lgrp)
 
-    // ---- which tile: workgroups are dealt to the 8 XCDs round-robin; XCD k takes the k-th contiguous eighth of the
-    // tiles, so that neighbouring tiles (shared halo rows and packets) meet in one L2 --------------------------------
-    const int per_xcd = (g.units + 7) >> 3;
+    // ---- which tiles: a workgroup is persistent and walks tiles.  Workgroups are dealt to the 8 XCDs round-robin; XCD k
+    // takes the k-th contiguous eighth of the tiles and its workgroups walk it side by side, so that neighbouring tiles
+    // (shared halo rows and packets) meet in one L2.  What a one-tile workgroup pays around its K loop - its dispatch,
+    // the round trip of the first chunk's loads, the drain of its stores before the CU takes the next workgroup - came
+    // to 9.5 us per tile against 3.6 us per chunk (a 128-channel layer has four chunks); here the next tile's first
+    // chunk is requested before the epilogue of the current one, whose stores drain beside the next K loop. ------------
+    const int per_xcd = (g.units + 7) >> 3, stride = gridDim.x >> 3;
+    const int unit_end = min(g.units, ((int)(blockIdx.x & 7) + 1) * per_xcd);
     int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= g.units) return;
-    const int tb = unit % g.tiles_b; unit /= g.tiles_b;
-    const int ta = unit % g.tiles_a; unit /= g.tiles_a;
-    const int n = unit % g.n;
-    const int m0 = (unit / g.n) * BMT;
-    const int a0 = ta * TH, b0 = tb * TW;
+    if (unit >= unit_end) return;
     const int plane = g.h * g.wid;
-    const T* __restrict__ xs = (const T*)g.x + (unsigned)(n * g.ci * plane);   // fewer than 2^31 elements per tensor
     const unsigned plane_bytes = (unsigned)plane * 2u;
+    auto decode = [&](int u, int& n, int& m0, int& ta, int& tb) {
+        u = __builtin_amdgcn_readfirstlane(u);      // (uniform: said once, so that what follows stays scalar)
+        tb = u % g.tiles_b; u /= g.tiles_b;
+        ta = u % g.tiles_a; u /= g.tiles_a;
+        n = u % g.n;
+        m0 = (u / g.n) * BMT;
+    };
 
     // ---- staging plan: lane = (channel pair cg = tid & 15, item slot tid >> 4); item = (footprint row, packet) -----
     // (ADJ = 2 at unit stride, where a footprint row has an even number of packets: neighbouring lanes take neighbouring
     // packets of one channel pair and row, so a load instruction touches half as many 32-byte runs: + 2-3 %)
-    const int cg = (tid / ADJ) & 15, slot0 = (tid / (16 * ADJ)) * ADJ + (tid % ADJ);
-    unsigned voff[STEPS];       // byte offset of the item's packet of channel 2 cg from the chunk's first channel
-    {
+    // What does not depend on the tile - an item's row and packet inside the footprint, its place in the LDS image - is
+    // decided here.  The item slots are a few more than the footprint has items and the image is padded to hold them
+    // all: a surplus item loads zeros and is written behind the footprint like any other (no branch around a commit).
+    int cg, slot0;
+    // LDS: item q lands in image rows (slot0 + SLOTS q) * 8 + j; the swizzle of such a row is that of j
+    int st_addr[4];             // byte address of the dword of pixel j = 2 jp (+ 64 for j = 2 jp + 1), item q = 0
+    // weights [tap][co][ci]: a lane moves, per tap, the 16-byte slot tid & 3 of output channel tid >> 2
+    int w_c, w_st;                                                  // w_st + tap * BMT * kRow (BMT is a multiple of 8)
+    const unsigned w_tap = (unsigned)(g.co * g.ci) * 2u;
+    const T* __restrict__ w = (const T*)g.w;
+    // multiply-phase addressing: n-tile j of wave w: output row 2w + (j >> 1), columns 16 (j & 1) .. +15; lane l
+    // addresses pixel column l & 15
+    int brow[4], a_lane;
+    auto lane_constants = [&]() {
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        wave = (tid >> 6) & 3; half = tid >> 8;
+        lrow = lane & 15; lgrp = lane >> 4;
+        cg = (tid / ADJ) & 15; slot0 = (tid / (16 * ADJ)) * ADJ + (tid % ADJ);
+#pragma unroll
+        for (int jp = 0; jp < 4; jp++) st_addr[jp] = slot0 * 8 * kRow + swz(2 * jp, cg * 4);
+        w_c = (tid & 3) * 8;
+        w_st = swz(tid >> 2, (tid & 3) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * STEP * LWP + ((j & 1) * 16 + lrow) * STEP + g.px_col;
+        a_lane = lrow * kRow + (((lgrp ^ (lrow >> 1)) & 3) << 4);
+    };
+
+    // The tile whose packets are being requested (the next one, once the current tile's last chunk is multiplied): byte
+    // offsets of the items' packets of channel 2 cg from a chunk's first channel, the lane's weight slot, the sample.
+    // A tile that does not exist (after a workgroup's last) is planned with everything outside: its loads return zeros
+    // without a memory access and the tile loop needs no branch around them.
+    unsigned voff[STEPS];
+    unsigned w_voff = kOutside;
+    int n_st = 0;
+    auto stage_plan = [&](int n, int m0, int a0, int b0, bool exists) {
         const int px_first = b0 * STEP + g.px_shift;                // first pixel column of the staged packets
         const int iy_first = a0 * STEP + g.dy0;
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
-            const int item = slot0 + SLOTS * q;
-            const int ry = item / NV, v = item - ry * NV;
-            const int iy = iy_first + ry, px0 = px_first + v * 8;
-            const bool ok = item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
+            const int item = slot0 + SLOTS * q, ry = item / NV;
+            const int iy = iy_first + ry, px0 = px_first + (item - ry * NV) * 8;
+            const bool ok = exists && item < G::ITEMS && iy >= 0 && iy < g.h && px0 >= 0 && px0 < g.wid;
             voff[q] = ok ? (unsigned)(2 * cg * plane + iy * g.wid + px0) * 2u : kOutside;
         }
-    }
-    const bool last_item = !LAST_PARTIAL || slot0 + SLOTS * (STEPS - 1) < G::ITEMS;
-    // LDS: item q lands in image rows (slot0 + SLOTS q) * 8 + j; the swizzle of such a row is that of j
-    int st_addr[4];             // byte address of the dword of pixel j = 2 jp (+ 64 for j = 2 jp + 1), item q = 0
-#pragma unroll
-    for (int jp = 0; jp < 4; jp++) st_addr[jp] = slot0 * 8 * kRow + swz(2 * jp, cg * 4);
-    // weights [tap][co][ci]: a lane moves, per tap, the 16-byte slot tid & 3 of output channel tid >> 2
-    const int w_o = m0 + (tid >> 2), w_c = (tid & 3) * 8;
-    const unsigned w_voff = (w_o < g.co) ? (unsigned)(w_o * g.ci + w_c) * 2u : kOutside;
-    const unsigned w_tap = (unsigned)(g.co * g.ci) * 2u;
-    const int w_st = swz(tid >> 2, (tid & 3) * 16);                 // + tap * BMT * kRow (BMT is a multiple of 8)
-    const T* __restrict__ w = (const T*)g.w;
+        n_st = exists ? n : 0;
+        const int w_o = m0 + (tid >> 2);
+        w_voff = (exists && w_o < g.co) ? (unsigned)(w_o * g.ci + w_c) * 2u : kOutside;
+    };
 
     uint4 va[STEPS], vb[STEPS], vw[9];
     float s0 = 1.f, s1 = 1.f;
@@ -223,16 +264,17 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
     // path of a CU takes 16 cycles per 16-byte load instruction of a wave, 8 waves x 15 loads = 1,900 cycles per chunk:
     // issued as one batch in front of the multiply phase, the loads queue there and the waves start multiplying one
     // after the other as their batches get through (cycle stamps: the last wave of a SIMD entered its multiply
-    // phase 3,000 cycles after the barrier, its SIMD partner waited 2,600 at the next one).  So only the first chunk is
-    // fetched as a batch; every other chunk's loads are dealt over the nine taps of the multiply phase before it
-    // (fetch_part), one or two instructions beside 16 matrix instructions.
-    rsrc_t d_x = make_rsrc(xs, 0u), d_s = make_rsrc(xs, 0u), d_w = make_rsrc(xs, 0u);
+    // phase 3,000 cycles after the barrier, its SIMD partner waited 2,600 at the next one).  So only a tile's first chunk
+    // is fetched as a batch (in front of the previous tile's epilogue); every other chunk's loads are dealt over the nine
+    // taps of the multiply phase before it (fetch_part), one or two instructions beside 16 matrix instructions.
+    rsrc_t d_x = make_rsrc(g.x, 0u), d_s = make_rsrc(g.x, 0u), d_w = make_rsrc(g.x, 0u);
     unsigned wv = kOutside;
     auto fetch_begin = [&](int c0) {
         const int left = min(KCH, g.ci - c0);                       // channels of this chunk
-        d_x = make_rsrc(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
-        if constexpr (MOD) d_s = make_rsrc(g.in_scale + (size_t)n * g.ci + c0, (unsigned)left * 4u);
-        d_w = make_rsrc(w + c0, 9u * w_tap);
+        const T* xs = (const T*)g.x + (unsigned)(n_st * g.ci * plane);   // fewer than 2^31 elements per tensor
+        d_x = make_rsrc_uniform(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
+        if constexpr (MOD) d_s = make_rsrc_uniform(g.in_scale + (size_t)n_st * g.ci + c0, (unsigned)left * 4u);
+        d_w = make_rsrc_uniform(w + c0, 9u * w_tap);
         wv = (w_c < left) ? w_voff : kOutside;       // the lane's slot of 8 channels lies in the chunk or not
     };
     auto fetch_part = [&](int t) {                   // t = 0 .. 8
@@ -258,7 +300,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
     auto commit = [&]() {
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
-            if (LAST_PARTIAL && q == STEPS - 1 && !last_item) continue;
             const unsigned wa[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
             const unsigned wb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
 #pragma unroll
@@ -280,36 +321,29 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
         for (int q = 0; q < 9; q++) *reinterpret_cast<uint4*>(s_w + w_st + q * (BMT * kRow)) = vw[q];
     };
 
-    // ---- multiply-phase addressing ----------------------------------------------------------------------
-    // n-tile j of wave w: output row 2w + (j >> 1), columns 16 (j & 1) .. +15; lane l addresses pixel column l & 15
-    int brow[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) brow[j] = (2 * wave + (j >> 1)) * STEP * LWP + ((j & 1) * 16 + lrow) * STEP + g.px_col;
-    const int a_lane = lrow * kRow + (((lgrp ^ (lrow >> 1)) & 3) << 4);
-
     f32x4_t acc[4][4];   // [channel tile m][pixel tile j]: rows = pixels 4 lgrp + r, column = channel lrow
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // ---- epilogue operands, loaded during the last multiply phase -----------------------------------------
+    // ---- the tile being multiplied: where its outputs go; epilogue operands, loaded during its last multiply phase ---
     // (The bias stays in its 16 bits until the epilogue: widened where it is loaded - inside the branch on g.bias - each
     // of the four loads would be waited for on the spot, four memory round trips in a row per workgroup.)
+    int n = 0, m0 = 0, ta = 0, tb = 0, a0 = 0, b0 = 0;
     float sc[4];
     unsigned bs[4];
     float4 nz[4];
     uint2 rx[4][4];
-    const int ch0 = m0 + 64 * half + lrow;
+    int ch0 = 0;
     const int ch_stride = 16 * g.oh * g.ow;
     unsigned off0[4];
     bool inside[4];
+    auto out_plan = [&]() {
+        ch0 = m0 + 64 * half + lrow;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int a = a0 + 2 * wave + (j >> 1), b = b0 + (j & 1) * 16 + 4 * lgrp;
-        inside[j] = a < g.oh && b < g.ow;
-        off0[j] = (unsigned)(((n * g.co + ch0) * g.oh + a) * g.ow + b);
-    }
+        for (int j = 0; j < 4; j++) {
+            const int a = a0 + 2 * wave + (j >> 1), b = b0 + (j & 1) * 16 + 4 * lgrp;
+            inside[j] = a < g.oh && b < g.ow;
+            off0[j] = (unsigned)(((n * g.co + ch0) * g.oh + a) * g.ow + b);
+        }
+    };
     auto fetch_epilogue = [&]() {
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -360,54 +394,79 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : Geo<STEP>::BLOCKS
         }
     };
 
-    fetch(0);
     const int c_last = ((g.ci - 1) / KCH) * KCH;
-    for (int c0 = 0; c0 < c_last; c0 += KCH) {
-        __syncthreads();   // everyone is done reading the previous chunk
+    const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
+    T* __restrict__ y = (T*)g.y;
+    lane_constants();
+    decode(unit, n, m0, ta, tb);
+    stage_plan(n, m0, ta * TH, tb * TW, true);
+    fetch(0);
+    for (;;) {
+        lane_constants();
+        a0 = ta * TH; b0 = tb * TW;
+        out_plan();
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < c_last; c0 += KCH) {
+            __syncthreads();   // everyone is done reading the previous chunk (or the previous tile's last)
+            commit();
+            __syncthreads();
+            fetch_begin(c0 + KCH);
+            multiply(std::true_type{});      // (the next chunk's loads are issued between its taps)
+        }
+        __syncthreads();
         commit();
         __syncthreads();
-        fetch_begin(c0 + KCH);
-        multiply(std::true_type{});      // (the next chunk's loads are issued between its taps)
-    }
-    __syncthreads();
-    commit();
-    __syncthreads();
-    fetch_epilogue();      // the last chunk's multiply phase covers the epilogue's loads instead
-    multiply(std::false_type{});
+        fetch_epilogue();      // the last chunk's multiply phase covers the epilogue's loads instead
+        multiply(std::false_type{});
 
-    // ---- epilogue: straight-line arithmetic (scale 1, noise 0, bias 0, slope 1, clamp +-inf are no-ops) -------
-    const float noise_gain = (g.noise && g.noise_gain) ? *g.noise_gain : 1.f;
-    float red[4] = {0.f, 0.f, 0.f, 0.f};
-    const float bsf[4] = {lo16<T>(bs[0]), lo16<T>(bs[1]), lo16<T>(bs[2]), lo16<T>(bs[3])};
-    T* __restrict__ y = (T*)g.y;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const f32x2_t nz01 = {nz[j].x * noise_gain, nz[j].y * noise_gain}, nz23 = {nz[j].z * noise_gain, nz[j].w * noise_gain};
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            if (!inside[j] || ch0 + 16 * m >= g.co) continue;
-            const f32x4_t v = acc[m][j];
-            if (g.reduce_out)
-                red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
-            *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = finish4<T>(v, sc[m], nz01, nz23, bsf[m], g.slope, g.gain, g.hi);
+        // ---- the next tile's first chunk goes out ahead of this tile's epilogue (loads return in order: the epilogue's
+        // wait for its operands, requested before the multiply phase, leaves these in flight) -----------------------
+        const int next = unit + stride;
+        const bool more = PERSISTENT && next < unit_end;
+        int n2 = n, m2 = m0, ta2 = ta, tb2 = tb;
+        if constexpr (PERSISTENT) decode(more ? next : unit, n2, m2, ta2, tb2);
+        if constexpr (PERSISTENT) {
+            stage_plan(n2, m2, ta2 * TH, tb2 * TW, more);
+            fetch(0);
         }
-    }
-    if (g.reduce_out) {
-        // lanes l, l+16, l+32, l+48 share their channels; then the four waves through LDS; one partial row per tile
-        __syncthreads();   // every wave has left the multiply loop; LDS can be reused
-        float* s_red = reinterpret_cast<float*>(smem);
+
+        // ---- epilogue: straight-line arithmetic (scale 1, noise 0, bias 0, slope 1, clamp +-inf are no-ops) -------
+        float red[4] = {0.f, 0.f, 0.f, 0.f};
+        const float bsf[4] = {lo16<T>(bs[0]), lo16<T>(bs[1]), lo16<T>(bs[2]), lo16<T>(bs[3])};
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            float r = red[m];
-            r += __shfl_xor(r, 16, 64);
-            r += __shfl_xor(r, 32, 64);
-            if (lgrp == 0) s_red[wave * BMT + 64 * half + m * 16 + lrow] = r;
+        for (int j = 0; j < 4; j++) {
+            const f32x2_t nz01 = {nz[j].x * noise_gain, nz[j].y * noise_gain}, nz23 = {nz[j].z * noise_gain, nz[j].w * noise_gain};
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (!inside[j] || ch0 + 16 * m >= g.co) continue;
+                const f32x4_t v = acc[m][j];
+                if (g.reduce_out)
+                    red[m] += v[0] * lo16<T>(rx[j][m].x) + v[1] * hi16<T>(rx[j][m].x) + v[2] * lo16<T>(rx[j][m].y) + v[3] * hi16<T>(rx[j][m].y);
+                *reinterpret_cast<uint2*>(y + off0[j] + m * ch_stride) = finish4<T>(v, sc[m], nz01, nz23, bsf[m], g.slope, g.gain, g.hi);
+            }
         }
-        __syncthreads();
-        if (tid < BMT && m0 + tid < g.co) {
-            const float r = s_red[tid] + s_red[BMT + tid] + s_red[2 * BMT + tid] + s_red[3 * BMT + tid];
-            g.reduce_out[((n * g.tiles_a + ta) * g.tiles_b + tb) * g.co + m0 + tid] = r;
+        if (g.reduce_out) {
+            // lanes l, l+16, l+32, l+48 share their channels; then the four waves through LDS; one partial row per tile
+            __syncthreads();   // every wave has left the multiply loop; LDS can be reused
+            float* s_red = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                float r = red[m];
+                r += __shfl_xor(r, 16, 64);
+                r += __shfl_xor(r, 32, 64);
+                if (lgrp == 0) s_red[wave * BMT + 64 * half + m * 16 + lrow] = r;
+            }
+            __syncthreads();
+            if (tid < BMT && m0 + tid < g.co) {
+                const float r = s_red[tid] + s_red[BMT + tid] + s_red[2 * BMT + tid] + s_red[3 * BMT + tid];
+                g.reduce_out[((n * g.tiles_a + ta) * g.tiles_b + tb) * g.co + m0 + tid] = r;
+            }
         }
+        if (!PERSISTENT || !more) break;
+        unit = next; n = n2; m0 = m2; ta = ta2; tb = tb2;
     }
 }
 
@@ -801,15 +860,19 @@ static int launch_resident_for(const Conv3x3Args& g, int64_t units, int ci, int 
 template <class T, int STEP, int WAVES, bool MOD>
 static int launch_step(Conv3x3Args g, hipStream_t stream) {
     constexpr int BMT = BM * (WAVES / 4);
-    constexpr size_t lds = Geo<STEP>::kInBytes + kWBytes * (WAVES / 4);
+    constexpr size_t lds = Geo<STEP>::kInPadded + kWBytes * (WAVES / 4);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS of a CU");
+    constexpr int per_cu = (WAVES == 8) ? 1 : Geo<STEP>::BLOCKS_PER_CU;
     const int64_t units = (int64_t)g.tiles_a * g.tiles_b * g.n * ((g.co + BMT - 1) / BMT);
     SG_REQUIRE(units <= INT32_MAX - 8, SG_ERR_INVALID_ARGUMENT, "conv2d: too many tiles");
     g.units = (int)units;
     auto kernel = conv3x3_kernel<T, STEP, WAVES, MOD, STEP == 1 ? 2 : 1>;
     hipError_t e = allow_large_lds((const void*)kernel);
     if (e != hipSuccess) return fail((int)e, "conv2d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 7) / 8 * 8)), dim3(64 * WAVES), lds, stream, g);
+    // persistent workgroups: as many as the device holds at once, a multiple of the 8 XCDs; else one per tile
+    const int64_t all = (units + 7) / 8 * 8;
+    const int64_t grid = conv3x3_persistent(STEP, WAVES) ? std::max<int64_t>(8, std::min<int64_t>(all, (int64_t)per_cu * compute_units()) / 8 * 8) : all;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * WAVES), lds, stream, g);
     return check_launch("sg_conv2d");
 }
 
