@@ -17,6 +17,9 @@
 #include "sg_common.h"
 #include "sg_conv3x3.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace sg {
 namespace {
 
@@ -90,6 +93,15 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ uint4 load16(rsrc_t r, unsigned voff, unsigned soff) {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant in every
+// iteration's own code, so that register arrays indexed by it are split into registers.
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 struct ConvUpArgs {
@@ -172,23 +184,40 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) conv_up2_kerne
     uint4 va[STEPS], vb[STEPS], vw[WQ];
     float s0 = 1.f, s1 = 1.f;
 
-    auto fetch = [&](int c0) {
+    // The loads of a chunk (2 STEPS input packets, two modulation scales, WQ weight packets per lane): the first chunk's
+    // as one batch, every other chunk's dealt over the four window offsets of the multiply phase before it - a batch in
+    // front of the phase queues in the texture path (16 cycles per 16-byte load of a wave) and staggers the waves.
+    rsrc_t d_x = make_rsrc(xs, 0u), d_s = make_rsrc(xs, 0u), d_w = make_rsrc(xs, 0u);
+    bool slot_ok = false;
+    auto fetch_begin = [&](int c0) {
         const int left = min(KCH, g.ci - c0);
-        const rsrc_t rx = make_rsrc(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
-#pragma unroll
-        for (int q = 0; q < STEPS; q++) {
-            va[q] = load16(rx, voff[q], 0);
-            vb[q] = load16(rx, voff[q], plane_bytes);
-        }
+        d_x = make_rsrc(xs + (size_t)c0 * plane, (unsigned)left * plane_bytes);
+        if constexpr (MOD) d_s = make_rsrc(g.in_scale + (size_t)n * g.ci + c0, (unsigned)left * 4u);
+        d_w = make_rsrc(w + c0, (unsigned)g.w_bytes);
+        slot_ok = w_slot * 8 < left;
+    };
+    constexpr int kLoads = 2 * STEPS + WQ;
+    auto fetch_part = [&](auto offset) __attribute__((always_inline)) {      // offset o = 0 .. 3: loads l with l * 4 / kLoads == o
+        constexpr int o = decltype(offset)::value;
+        static_for<kLoads>([&](auto load) __attribute__((always_inline)) {
+            constexpr int l = decltype(load)::value;
+            if constexpr ((l * 4) / kLoads == o) {
+                if constexpr (l < 2 * STEPS) {
+                    if constexpr (l & 1) vb[l >> 1] = load16(d_x, voff[l >> 1], plane_bytes);
+                    else va[l >> 1] = load16(d_x, voff[l >> 1], 0);
+                } else {
+                    vw[l - 2 * STEPS] = load16(d_w, slot_ok ? w_voff[l - 2 * STEPS] : kOutside, 0);
+                }
+            }
+        });
         if constexpr (MOD) {
-            const rsrc_t rs = make_rsrc(g.in_scale + (size_t)n * g.ci + c0, (unsigned)left * 4u);
-            s0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 0, 0));
-            s1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cg * 8, 4, 0));
+            if constexpr (o == 1) s0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s, cg * 8, 0, 0));
+            if constexpr (o == 2) s1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d_s, cg * 8, 4, 0));
         }
-        const rsrc_t rw = make_rsrc(w + c0, (unsigned)g.w_bytes);
-        const bool slot_ok = w_slot * 8 < left;
-#pragma unroll
-        for (int q = 0; q < WQ; q++) vw[q] = load16(rw, slot_ok ? w_voff[q] : kOutside, 0);
+    };
+    auto fetch = [&](int c0) {
+        fetch_begin(c0);
+        static_for<4>([&](auto o) __attribute__((always_inline)) { fetch_part(o); });
     };
     auto commit = [&]() {
 #pragma unroll
@@ -231,18 +260,19 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) conv_up2_kerne
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[p][ct][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto multiply = [&]() {
+    auto multiply = [&](auto with_fetch) __attribute__((always_inline)) {
         // window offset outermost: its 4 input fragments serve every (phase, tap) combination that reads it
-        constexpr Combo kc[kCombos] = {{0, 0, 0, -1, -1}, {0, 0, 1, -1, 0}, {0, 1, 0, 0, -1}, {0, 1, 1, 0, 0}, {1, 0, 0, -1, 0},
-                                       {1, 1, 0, 0, 0}, {2, 0, 0, 0, -1}, {2, 0, 1, 0, 0}, {3, 0, 0, 0, 0}};
-#pragma unroll
-        for (int o = 0; o < 4; o++) {   // o = 2 (dy + 1) + (dx + 1)
+        static_for<4>([&](auto offset) __attribute__((always_inline)) {   // o = 2 (dy + 1) + (dx + 1)
+            constexpr int o = decltype(offset)::value;
+            constexpr Combo kc[kCombos] = {{0, 0, 0, -1, -1}, {0, 0, 1, -1, 0}, {0, 1, 0, 0, -1}, {0, 1, 1, 0, 0}, {1, 0, 0, -1, 0},
+                                           {1, 1, 0, 0, 0}, {2, 0, 0, 0, -1}, {2, 0, 1, 0, 0}, {3, 0, 0, 0, 0}};
             uint4 fb[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = brow[j] + ((o >> 1) - 1) * LWP + (o & 1) - 1;
                 fb[j] = *reinterpret_cast<const uint4*>(s_in + row * kRow + (((lgrp ^ (row >> 1)) & 3) << 4));
             }
+            if constexpr (decltype(with_fetch)::value) fetch_part(offset);
 #pragma unroll
             for (int combo = 0; combo < kCombos; combo++) {
                 if (2 * (kc[combo].dy + 1) + kc[combo].dx + 1 != o) continue;
@@ -256,17 +286,22 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) conv_up2_kerne
                     for (int ct = 0; ct < 2; ct++) Mma16<T>::run(fb[j], fa[ct], acc[p][ct][j]);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
 
     fetch(0);
-    for (int c0 = 0; c0 < g.ci; c0 += KCH) {
+    const int c_last = ((g.ci - 1) / KCH) * KCH;
+    for (int c0 = 0; c0 < c_last; c0 += KCH) {
         __syncthreads();
         commit();
         __syncthreads();
-        if (c0 + KCH < g.ci) fetch(c0 + KCH);   // in flight during the multiply phase
-        multiply();
+        fetch_begin(c0 + KCH);
+        multiply(std::true_type{});     // (the next chunk's loads go out between its window offsets)
     }
+    __syncthreads();
+    commit();
+    __syncthreads();
+    multiply(std::false_type{});
 
     // ---- store: both px phases of a channel interleave into 8 consecutive output pixels -----------------------
     T* __restrict__ y = (T*)g.y;
