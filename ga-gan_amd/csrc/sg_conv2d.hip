@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
     // pixel fragments of the next step and - two steps before a tap ends - the weight fragments of the next tap are
     // read into a second register set while the 12 matrix instructions of the current step run.
     // (the images are named by their byte offsets in smem, so that the reads stay LDS instructions)
-    auto split_multiply = [&](int w_off, int x_off, int g0, int gtaps) {
+    auto split_multiply = [&](int w_off, int x_off, int g0, int gtaps, auto&& beside_first_tap) {
         const unsigned char* s_w = smem + w_off;
         const unsigned char* s_in = smem + x_off;
         int tap_row[kSplitTaps];
@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
                 if (j + 1 < NT) read_b(tl, j + 1, b[(step + 1) & 1]);
                 else if (tl + 1 < gtaps) read_b(tl + 1, 0, b[(step + 1) & 1]);
                 if (j == kAhead && tl + 1 < gtaps) read_a(tl + 1, a[(tl + 1) & 1]);
+                if (tl == 0) beside_first_tap(j);                     // (global loads of the caller, a few per step)
                 __builtin_amdgcn_sched_barrier(0);                    // (reads first: they have the whole step to land)
 #pragma unroll
                 for (int m = 0; m < M_TILES; m++) mma_split(a[tl & 1][m], b[step & 1], acc[m][j]);
@@ -448,6 +449,18 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
 #pragma unroll
             for (int k = 0; k < X_IT; k++) xreg[k] = x_fetch(cb, xoff[k]);
         };
+        // The next chunk's footprint pieces, dealt over the NT steps of a stage's first tap (as one batch in front of
+        // the stage they queue in the texture path, 16 cycles per load of a wave, and the waves start multiplying one
+        // after the other); cb < 0: none wanted in this stage.
+        int x_next = -1;
+        auto x_load_part = [&](int j) {
+            if (x_next < 0) return;
+#pragma unroll
+            for (int k = 0; k < X_IT; k++) {
+                if ((k * NT) / X_IT != j) continue;
+                xreg[k] = x_fetch(x_next, xoff[k]);
+            }
+        };
         auto x_commit = [&](int x_off, int cb) {
             unsigned char* s_in = smem + x_off;
 #pragma unroll
@@ -492,8 +505,8 @@ __global__ void __launch_bounds__(conv_threads<T>(), sizeof(T) == 4 ? 1 : 2) con
         while (cb < cb_end) {
             const bool first = g0 == 0, last = cb1 != cb;
             if (cb1 < cb_end) w_issue(cb1, g1, s_wb(sidx + 1));
-            if (first && cb + 1 < cb_end) x_load(cb + 1);
-            split_multiply(s_wb(sidx), s_x(cb), g0, min(kSplitTaps, taps - g0));
+            x_next = (first && cb + 1 < cb_end) ? cb + 1 : -1;
+            split_multiply(s_wb(sidx), s_x(cb), g0, min(kSplitTaps, taps - g0), x_load_part);
             if (last && cb1 < cb_end) {
                 if (!t.x_double) __syncthreads();   // every wave has read the footprint of this chunk
                 x_commit(s_x(cb1), cb1);
