@@ -311,15 +311,18 @@ def supports_mask(x, plan, co, out_hw=None, reduce=False):
     return bool(_lib.lib().sg_conv2d_supports_mask(ctypes.byref(p)))
 
 
-def supports_addend(x, plan, co, out_hw=None, epilogue_free=True):
-    """True when `conv2d(x, ..., addend=...)` has a kernel for this geometry (no modulation, no noise)."""
+def supports_addend(x, plan, co, out_hw=None, epilogue_free=True, reduce=False, mask=False):
+    """True when `conv2d(x, ..., addend=...)` has a kernel for this geometry: 1x1 layers without modulation or noise, and
+    1x1 layers with three input channels (the data gradient of a to-RGB layer; `reduce`: with the style-gradient
+    reduction, `mask`: with an activation mask on the input)."""
     if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in _DTYPE_NAME:
         return False
     n, ci, h, w = x.shape
     oh, ow = plan.out_size(h, w) if out_hw is None else out_hw
     p = Conv2dParams(x=_lib.ptr(x), w=_lib.ptr(x), y=_lib.ptr(x), addend=_lib.ptr(x), dtype=_lib.dtype_code(x), n=n, ci=ci, h=h,
                      w_in=w, co=co, oh=oh, ow=ow, in_step=plan.in_step, out_step=plan.out_step, num_phases=len(plan.phases),
-                     act=1, gain=1.0, clamp=-1.0, mask_clamp=-1.0)
+                     act=1, gain=1.0, clamp=-1.0, mask_clamp=-1.0, reduce_x=_lib.ptr(x) if reduce else None,
+                     mask_y=_lib.ptr(x) if mask else None)
     offset = 0
     for i, (oy0, ox0, dy0, dx0, nky, nkx, _, _) in enumerate(plan.phases):
         p.phase[i] = Phase(oy0, ox0, dy0, dx0, nky, nkx, offset)

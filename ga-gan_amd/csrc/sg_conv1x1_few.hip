@@ -78,6 +78,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 struct FewArgs {
     const void* x; const void* mask_y; const void* w; void* y;
     const float* in_scale; const float* out_scale; const void* bias; const void* reduce_x; float* reduce_out;
+    const void* addend;           // few_in only: a tensor of y's shape added to the rounded result (or null)
     int n, ci, co;
     int packets;                  // 8-pixel packets per plane
     float slope, gain, hi, m_slope, m_hi;
@@ -151,7 +152,9 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_out_kernel(FewArgs g)
 
 // ---- few_in: every lane 8 pixels (times several packets), loop over the output channels ---------------------------------
 // CO_R: compile-time bound of the output channels when the reduction is wanted (its partial sums live in registers)
-template <class T, int CI, bool MASK, int CO_R>
+// ADD: y = round(round(result) + addend) - the arithmetic of a separate sum of two 16-bit tensors (the data gradient of
+// a to-RGB layer meets the other gradient of its input here instead of in a pass of its own)
+template <class T, int CI, bool MASK, int CO_R, bool ADD>
 __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) {
     extern __shared__ float s_few[];            // [co][CI] weights x in_scale, then [co] out_scale x gain, [co] bias x gain
     float* s_w = s_few;
@@ -173,6 +176,7 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
     const T* __restrict__ mn = MASK ? (const T*)g.mask_y + (int64_t)n * CI * plane : nullptr;
     const T* __restrict__ rn = (CO_R > 0) ? (const T*)g.reduce_x + (int64_t)n * g.co * plane : nullptr;
     T* __restrict__ yn = (T*)g.y + (int64_t)n * g.co * plane;
+    const T* __restrict__ an = ADD ? (const T*)g.addend + (int64_t)n * g.co * plane : nullptr;
     float red[CO_R > 0 ? CO_R : 1];
 #pragma unroll
     for (int o = 0; o < (CO_R > 0 ? CO_R : 1); o++) red[o] = 0.f;
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
             unpack8<T>(*reinterpret_cast<const uint4*>(xn + c * plane + (int64_t)pk * 8), xin[c]);
             if constexpr (MASK) mask8<T>(xin[c], *reinterpret_cast<const uint4*>(mn + c * plane + (int64_t)pk * 8), g.m_slope, g.m_hi);
         }
-        auto one = [&](int o, const uint4& rxv) {
+        auto one = [&](int o, const uint4& rxv, const uint4& addv) {
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] = 0.f;
@@ -208,25 +212,59 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
                 z = __builtin_fmaxf(z, z * g.slope);
                 acc[j] = __builtin_amdgcn_fmed3f(z, -g.hi, g.hi);
             }
-            *reinterpret_cast<uint4*>(yn + o * plane + (int64_t)pk * 8) = pack8<T>(acc);
+            uint4 out = pack8<T>(acc);
+            if constexpr (ADD) {
+                float a[8], b[8];
+                unpack8<T>(out, a);
+                unpack8<T>(addv, b);
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] += b[j];
+                out = pack8<T>(a);
+            }
+            *reinterpret_cast<uint4*>(yn + o * plane + (int64_t)pk * 8) = out;
             return r;
         };
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
         if constexpr (CO_R > 0) {
-            // the reduction packets of the next four channels are requested before this group's arithmetic and stores
-            uint4 rxv[2][4];
+            // the reduction (and addend) packets of the next four channels are requested before this group's arithmetic and stores
+            uint4 rxv[2][4], adv[2][4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) rxv[0][u] = *reinterpret_cast<const uint4*>(rn + u * plane + (int64_t)pk * 8);
+            for (int u = 0; u < 4; u++) {
+                rxv[0][u] = *reinterpret_cast<const uint4*>(rn + u * plane + (int64_t)pk * 8);
+                adv[0][u] = ADD ? *reinterpret_cast<const uint4*>(an + u * plane + (int64_t)pk * 8) : zero4;
+            }
 #pragma unroll
             for (int o0 = 0; o0 < CO_R; o0 += 4) {
                 if (o0 + 4 < CO_R) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) rxv[((o0 >> 2) + 1) & 1][u] = *reinterpret_cast<const uint4*>(rn + (o0 + 4 + u) * plane + (int64_t)pk * 8);
+                    for (int u = 0; u < 4; u++) {
+                        rxv[((o0 >> 2) + 1) & 1][u] = *reinterpret_cast<const uint4*>(rn + (o0 + 4 + u) * plane + (int64_t)pk * 8);
+                        adv[((o0 >> 2) + 1) & 1][u] = ADD ? *reinterpret_cast<const uint4*>(an + (o0 + 4 + u) * plane + (int64_t)pk * 8) : zero4;
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) red[o0 + u] += one(o0 + u, rxv[(o0 >> 2) & 1][u]);
+                for (int u = 0; u < 4; u++) red[o0 + u] += one(o0 + u, rxv[(o0 >> 2) & 1][u], adv[(o0 >> 2) & 1][u]);
+            }
+        } else if constexpr (ADD) {
+            // groups of four output channels (co is a multiple of 4 with an addend, checked by the dispatcher), the next
+            // group's addend packets requested before this group's arithmetic and stores
+            uint4 adv[2][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) adv[0][u] = *reinterpret_cast<const uint4*>(an + u * plane + (int64_t)pk * 8);
+            for (int o0 = 0; o0 < g.co; o0 += 8) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int ob = o0 + 4 * h;
+                    if (ob >= g.co) break;
+                    const int nb = min(ob + 4, g.co - 4);      // (the last group requests itself again: no branch around the loads)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) adv[(h + 1) & 1][u] = *reinterpret_cast<const uint4*>(an + (nb + u) * plane + (int64_t)pk * 8);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) one(ob + u, zero4, adv[h][u]);
+                }
             }
         } else {
-            for (int o = 0; o < g.co; o++) one(o, make_uint4(0, 0, 0, 0));
+            for (int o = 0; o < g.co; o++) one(o, zero4, zero4);
         }
     }
     if constexpr (CO_R > 0) {
@@ -381,6 +419,7 @@ FewArgs few_args(const sg_conv2d_params& p) {
     g.x = p.x; g.mask_y = p.mask_y; g.w = p.w; g.y = p.y;
     g.in_scale = p.in_scale; g.out_scale = p.out_scale; g.bias = p.bias;
     g.reduce_x = p.reduce_out ? p.reduce_x : nullptr; g.reduce_out = p.reduce_x ? p.reduce_out : nullptr;
+    g.addend = p.addend;
     g.n = p.n; g.ci = p.ci; g.co = p.co;
     g.packets = (int)((int64_t)p.h * p.w_in / 8);
     g.slope = (p.act == 3) ? p.alpha : 1.f;
@@ -404,11 +443,19 @@ int launch_few_in(const FewArgs& g, hipStream_t stream) {
     // a lane keeps its reduction sums over several packets; without a reduction one packet per lane
     const int per_lane = g.reduce_out ? 8 : 1;
     const dim3 grid((unsigned)std::max(1, (g.packets + kFewThreads * per_lane - 1) / (kFewThreads * per_lane)), (unsigned)g.n);
+    if constexpr (CI == 3) {      // (the addend form exists for three channels: the to-RGB layers)
+        if (g.addend) {
+            if (!g.reduce_out) hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 0, true>), grid, dim3(kFewThreads), lds, stream, g);
+            else if (g.co == 32) hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 32, true>), grid, dim3(kFewThreads), lds, stream, g);
+            else hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 64, true>), grid, dim3(kFewThreads), lds, stream, g);
+            return check_launch("sg_conv2d");
+        }
+    }
     if (g.reduce_out) {
-        if (g.co == 32) hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 32>), grid, dim3(kFewThreads), lds, stream, g);
-        else hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 64>), grid, dim3(kFewThreads), lds, stream, g);
+        if (g.co == 32) hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 32, false>), grid, dim3(kFewThreads), lds, stream, g);
+        else hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 64, false>), grid, dim3(kFewThreads), lds, stream, g);
     } else {
-        hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 0>), grid, dim3(kFewThreads), lds, stream, g);
+        hipLaunchKernelGGL((conv1x1_few_in_kernel<T, CI, MASK, 0, false>), grid, dim3(kFewThreads), lds, stream, g);
     }
     return check_launch("sg_conv2d");
 }
@@ -438,12 +485,13 @@ int launch_few(const sg_conv2d_params& p, hipStream_t stream) {
 bool conv1x1_few_eligible(const sg_conv2d_params& p) {
     if (!common_ok(p)) return false;
     if (p.co <= 4 && p.ci > 4) {                                   // few_out
-        return p.ci <= kFewOutMaxCi && !p.mask_y && !p.reduce_x;
+        return p.ci <= kFewOutMaxCi && !p.mask_y && !p.reduce_x && !p.addend;
     }
     if (p.ci <= 4 && p.co > 4) {                                   // few_in
         if (p.co > 1024) return false;
         // (decided by reduce_x, which callers set before they size reduce_out with sg_conv2d_reduce_rows)
         if (p.reduce_x && p.co != 32 && p.co != 64) return false;
+        if (p.addend && (p.ci != 3 || p.co % 4 != 0 || !aligned16(p.addend))) return false;
         return true;
     }
     return false;

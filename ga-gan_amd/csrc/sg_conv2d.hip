@@ -1142,7 +1142,9 @@ extern "C" int sg_conv2d(const sg_conv2d_params* p, sg_stream_t stream) {
     if (p->n == 0) return SG_OK;
     SG_REQUIRE(p->x && p->w && p->y, SG_ERR_NULL_POINTER, "conv2d: x, w and y must not be NULL");
     if (p->addend != nullptr) {
-        SG_REQUIRE(pointwise_eligible(*p), SG_ERR_UNSUPPORTED, "conv2d: no kernel adds a tensor to the result for this geometry");
+        if (conv1x1_few_eligible(*p)) return conv1x1_few_launch(*p, (hipStream_t)stream);
+        SG_REQUIRE(p->mask_y == nullptr && pointwise_eligible(*p), SG_ERR_UNSUPPORTED,
+                   "conv2d: no kernel adds a tensor to the result for this geometry");
         return pointwise_launch(*p, (hipStream_t)stream);
     }
     if (conv1x1_few_eligible(*p)) return conv1x1_few_launch(*p, (hipStream_t)stream);
@@ -1236,7 +1238,10 @@ extern "C" int sg_conv2d_reduce_rows(const sg_conv2d_params* p) {
 
 extern "C" int sg_conv2d_supports_addend(const sg_conv2d_params* p) {
     if (p == nullptr || p->num_phases < 1 || p->num_phases > 4) return 0;
-    return sg::pointwise_eligible(*p) ? 1 : 0;
+    sg_conv2d_params q = *p;
+    if (q.addend == nullptr) q.addend = q.y;       // (asked before the addend exists: any aligned pointer stands in)
+    if (sg::conv1x1_few_eligible(q)) return 1;
+    return (q.mask_y == nullptr && sg::pointwise_eligible(q)) ? 1 : 0;
 }
 
 extern "C" int sg_conv2d_supports_mask(const sg_conv2d_params* p) {

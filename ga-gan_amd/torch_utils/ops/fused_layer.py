@@ -159,92 +159,127 @@ class _FusedConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, styles, dcoefs, noise, noise_strength, bias, f, y = ctx.saved_tensors
-        if ctx.w_memo is not None and not hasattr(w, '_sg_memo'):
-            w._sg_memo = ctx.w_memo
-        cfg = ctx.cfg
-        mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
-        need = ctx.needs_input_grad   # x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg, addend
-        d_addend = dy if len(need) > 9 and need[9] else None
+        return _backward(ctx, dy, None)
 
-        if torch.is_grad_enabled():   # a higher-order graph is wanted: differentiate the composite instead
-            with torch.enable_grad():
-                # Differentiate with respect to aliases of the inputs: an input may be an ancestor of another
-                # (the demodulation coefficients are computed from the styles and the weight), and the gradient
-                # returned for it must hold the direct dependence only - the caller's graph adds the rest.
-                alias = lambda t: t.view_as(t) if t is not None else None
-                ins = [alias(x), alias(w), alias(styles), alias(dcoefs), None, alias(noise_strength), alias(bias)]
-                out = _composite(ins[0], ins[1], ins[2], ins[3], noise, ins[5], ins[6], f, cfg)
-                wanted = [i for i in range(7) if need[i] and ins[i] is not None]
-                grads = torch.autograd.grad(out, [ins[i] for i in wanted], dy, create_graph=True, allow_unused=True)
-            result = [None] * 10
-            for i, g in zip(wanted, grads):
-                result[i] = g
-            result[9] = d_addend
-            return tuple(result)
 
-        ep = dict(scale=dcoefs, noise=noise, noise_gain=noise_strength if noise is not None else None, bias=bias, act=act,
-                  alpha=alpha, gain=gain, clamp=clamp)
-        want = dict(want_dbias=need[6] and bias is not None, want_dscale=need[3] and dcoefs is not None,
-                    want_dnoise_gain=need[5] and noise is not None and noise_strength is not None)
-        dx = dw = dstyles = None
-        ci = x.shape[1]
-        want_ds = need[2] and styles is not None
-        want_dx = need[0] or want_ds
-        dy = dy.contiguous()
-        # The activation mask applied to dy while the kernels stage it: no dz tensor.  Taken for 1x1 layers when a
-        # masking kernel exists for every gradient that is wanted (data gradient, weight gradient) at this geometry.
-        # (3x3 layers: the masking variants of the band and row kernels read dy and y and mask in registers beside
-        # their matrix instructions; writing dz once and reading it twice measured faster - 6.0 against 8.1 ms for
-        # the 32-channel layer at 1024 x 1024, 32 samples.)
-        if mode == 'same' and k == 1 and y is not None and (want_dx or need[1]):
-            plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
-            ok = not want_dx or (tuple(x.shape[2:]) == plan.out_size(*dy.shape[2:]) and _conv.supports_mask(dy, plan, ci, reduce=want_ds))
-            ok = ok and (not need[1] or _conv.wgrad_supports_mask(x, dy, k, k, stride=stride, padding=padding))
-            if ok:
-                mask = dict(mask_y=y, mask_alpha=alpha if act == 'lrelu' else 1.0, mask_clamp=clamp)
-                ddcoefs = dng = dbias = None
-                if any(want.values()):
-                    _, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y, want_dz=False, **want, **ep)
-                if want_dx:
-                    dx = _conv.conv2d(dy, plan.pack(w, transposed_layout=True), plan, ci, in_scale=dcoefs, out_scale=styles, gain=gain,
-                                      reduce_x=x if want_ds else None, **mask)
-                    if want_ds:
-                        dx, dstyles = dx
-                        dstyles = dstyles * gain      # the reduction is taken before the output scale and gain
-                if need[1]:
-                    dw = (_conv.conv2d_wgrad(x, dy, k, k, stride=stride, padding=padding, x_scale=styles, g_scale=dcoefs, **mask)
-                          * gain).to(w.dtype)
-                return (dx if need[0] else None, dw, dstyles, ddcoefs, None,
-                        dng.reshape(noise_strength.shape) if dng is not None else None,
-                        dbias.to(bias.dtype) if dbias is not None else None, None, None, d_addend)
-        dz, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y if y is not None else dy, **want, **ep)
-        if mode == 'same':
+class _FusedConvBranch(torch.autograd.Function):
+    """(x, layer(x)) for an input that has a second consumer - the output of a synthesis block feeds its to-RGB layer and
+    the next block (training/networks.py:1041-1046).  The gradient of such a tensor is the sum of what its consumers
+    return, which autograd forms in a pass of its own (read two tensors, write one).  Here the gradient that arrived for
+    the passed-through x is handed to the layer's data-gradient kernel, which adds it while it stores (1x1 layers with
+    three output channels; elsewhere the sum is a separate step as before).  Same arguments as `_FusedConv`."""
+
+    @staticmethod
+    def forward(ctx, x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg):
+        y = _FusedConv.forward(ctx, x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, gx, dy):
+        if dy is None:
+            return (gx if ctx.needs_input_grad[0] else None,) + (None,) * 8
+        return _backward(ctx, dy, gx)[:9]
+
+
+def _plus(a, b):
+    if a is None or b is None:
+        return a if b is None else b
+    return a + b
+
+
+def _backward(ctx, dy, gx):
+    """Gradients of `_FusedConv` / `_FusedConvBranch`; `gx`: gradient of the passed-through input (or None), added to
+    the input's gradient."""
+    x, w, styles, dcoefs, noise, noise_strength, bias, f, y = ctx.saved_tensors
+    if ctx.w_memo is not None and not hasattr(w, '_sg_memo'):
+        w._sg_memo = ctx.w_memo
+    cfg = ctx.cfg
+    mode, k, stride, padding, out_hw, act, alpha, gain, clamp, blur_pad, extra = cfg
+    need = ctx.needs_input_grad   # x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg, addend
+    d_addend = dy if len(need) > 9 and need[9] else None
+
+    if torch.is_grad_enabled():   # a higher-order graph is wanted: differentiate the composite instead
+        with torch.enable_grad():
+            # Differentiate with respect to aliases of the inputs: an input may be an ancestor of another
+            # (the demodulation coefficients are computed from the styles and the weight), and the gradient
+            # returned for it must hold the direct dependence only - the caller's graph adds the rest.
+            alias = lambda t: t.view_as(t) if t is not None else None
+            ins = [alias(x), alias(w), alias(styles), alias(dcoefs), None, alias(noise_strength), alias(bias)]
+            out = _composite(ins[0], ins[1], ins[2], ins[3], noise, ins[5], ins[6], f, cfg)
+            wanted = [i for i in range(7) if need[i] and ins[i] is not None]
+            grads = torch.autograd.grad(out, [ins[i] for i in wanted], dy, create_graph=True, allow_unused=True)
+        result = [None] * 10
+        for i, g in zip(wanted, grads):
+            result[i] = g
+        if need[0]:
+            result[0] = _plus(result[0], gx)
+        result[9] = d_addend
+        return tuple(result)
+
+    ep = dict(scale=dcoefs, noise=noise, noise_gain=noise_strength if noise is not None else None, bias=bias, act=act,
+              alpha=alpha, gain=gain, clamp=clamp)
+    want = dict(want_dbias=need[6] and bias is not None, want_dscale=need[3] and dcoefs is not None,
+                want_dnoise_gain=need[5] and noise is not None and noise_strength is not None)
+    dx = dw = dstyles = None
+    ci = x.shape[1]
+    want_ds = need[2] and styles is not None
+    want_dx = need[0] or want_ds
+    dy = dy.contiguous()
+    # The activation mask applied to dy while the kernels stage it: no dz tensor.  Taken for 1x1 layers when a
+    # masking kernel exists for every gradient that is wanted (data gradient, weight gradient) at this geometry.
+    # (3x3 layers: the masking variants of the band and row kernels read dy and y and mask in registers beside
+    # their matrix instructions; writing dz once and reading it twice measured faster - 6.0 against 8.1 ms for
+    # the 32-channel layer at 1024 x 1024, 32 samples.)
+    if mode == 'same' and k == 1 and y is not None and (want_dx or need[1]):
+        plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
+        ok = not want_dx or (tuple(x.shape[2:]) == plan.out_size(*dy.shape[2:]) and _conv.supports_mask(dy, plan, ci, reduce=want_ds))
+        ok = ok and (not need[1] or _conv.wgrad_supports_mask(x, dy, k, k, stride=stride, padding=padding))
+        if ok:
+            mask = dict(mask_y=y, mask_alpha=alpha if act == 'lrelu' else 1.0, mask_clamp=clamp)
+            ddcoefs = dng = dbias = None
+            if any(want.values()):
+                _, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y, want_dz=False, **want, **ep)
             if want_dx:
-                plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
-                dx = _conv.conv2d(dz, plan.pack(w, transposed_layout=True), plan, ci, out_scale=styles,
-                                  out_hw=tuple(x.shape[2:]), reduce_x=x if want_ds else None)
+                add = None
+                if gx is not None and need[0] and _conv.supports_addend(dy, plan, ci, reduce=want_ds, mask=True):
+                    add, gx = gx.contiguous(), None      # (the kernel adds it while it stores)
+                dx = _conv.conv2d(dy, plan.pack(w, transposed_layout=True), plan, ci, in_scale=dcoefs, out_scale=styles, gain=gain,
+                                  reduce_x=x if want_ds else None, addend=add, **mask)
+                if want_ds:
+                    dx, dstyles = dx
+                    dstyles = dstyles * gain      # the reduction is taken before the output scale and gain
             if need[1]:
-                dw = _conv.conv2d_wgrad(x, dz, k, k, stride=stride, padding=padding, x_scale=styles).to(w.dtype)
-        else:
-            fw, fh = _get_filter_size(f)
-            _, _, th, tw = ctx.t_shape
-            oh, ow = dz.shape[2:]
-            px0, px1, py0, py1 = blur_pad
-            dt = _fir.upfirdn2d(dz, f, 1, 1, 1, 1, fw - px0 - 1, tw - ow + px0, fh - py0 - 1, th - oh + py0, True, 4.0)
-            if want_dx:
-                plan = _conv.plan_conv(k, k, stride=2, padding=0)
-                packed = memo.memo(w, ('pack^T', plan.key), lambda: plan.pack(w.transpose(0, 1)))
-                dx = _conv.conv2d(dt, packed, plan, ci, out_scale=styles, out_hw=tuple(x.shape[2:]),
-                                  reduce_x=x if want_ds else None)
-            if need[1]:   # weight of the transposed conv is w^T [ci, co]; exchange the operands' roles
-                dw = _conv.conv2d_wgrad(dt, x, k, k, stride=2, padding=0, g_scale=styles).transpose(0, 1).to(w.dtype)
-        if want_ds and dx is not None:
-            dx, dstyles = dx
-        if not need[0]:
-            dx = None
-        return (dx, dw, dstyles, ddcoefs, None, dng.reshape(noise_strength.shape) if dng is not None else None,
-                dbias.to(bias.dtype) if dbias is not None else None, None, None, d_addend)
+                dw = (_conv.conv2d_wgrad(x, dy, k, k, stride=stride, padding=padding, x_scale=styles, g_scale=dcoefs, **mask)
+                      * gain).to(w.dtype)
+            return (_plus(dx, gx) if need[0] else None, dw, dstyles, ddcoefs, None,
+                    dng.reshape(noise_strength.shape) if dng is not None else None,
+                    dbias.to(bias.dtype) if dbias is not None else None, None, None, d_addend)
+    dz, dbias, ddcoefs, dng = _layer.epilogue_backward(dy, y if y is not None else dy, **want, **ep)
+    if mode == 'same':
+        if want_dx:
+            plan = _conv.plan_conv_transpose(k, k, stride=stride, padding=padding)
+            dx = _conv.conv2d(dz, plan.pack(w, transposed_layout=True), plan, ci, out_scale=styles,
+                              out_hw=tuple(x.shape[2:]), reduce_x=x if want_ds else None)
+        if need[1]:
+            dw = _conv.conv2d_wgrad(x, dz, k, k, stride=stride, padding=padding, x_scale=styles).to(w.dtype)
+    else:
+        fw, fh = _get_filter_size(f)
+        _, _, th, tw = ctx.t_shape
+        oh, ow = dz.shape[2:]
+        px0, px1, py0, py1 = blur_pad
+        dt = _fir.upfirdn2d(dz, f, 1, 1, 1, 1, fw - px0 - 1, tw - ow + px0, fh - py0 - 1, th - oh + py0, True, 4.0)
+        if want_dx:
+            plan = _conv.plan_conv(k, k, stride=2, padding=0)
+            packed = memo.memo(w, ('pack^T', plan.key), lambda: plan.pack(w.transpose(0, 1)))
+            dx = _conv.conv2d(dt, packed, plan, ci, out_scale=styles, out_hw=tuple(x.shape[2:]),
+                              reduce_x=x if want_ds else None)
+        if need[1]:   # weight of the transposed conv is w^T [ci, co]; exchange the operands' roles
+            dw = _conv.conv2d_wgrad(dt, x, k, k, stride=2, padding=0, g_scale=styles).transpose(0, 1).to(w.dtype)
+    if want_ds and dx is not None:
+        dx, dstyles = dx
+    dx = _plus(dx, gx) if need[0] else None
+    return (dx, dw, dstyles, ddcoefs, None, dng.reshape(noise_strength.shape) if dng is not None else None,
+            dbias.to(bias.dtype) if dbias is not None else None, None, None, d_addend)
 
 
 def _down_padding(f, k, padding, down=2):
@@ -262,14 +297,17 @@ def branch_down(x, f, padding=0):
 
 
 def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=None, dcoefs=None, noise=None,
-               noise_strength=None, bias=None, act='linear', alpha=None, gain=None, clamp=None, prefiltered=False, addend=None):
+               noise_strength=None, bias=None, act='linear', alpha=None, gain=None, clamp=None, prefiltered=False, addend=None,
+               also_input=False):
     """clamp(act(conv2d_resample(x * styles, w, f, up, down, padding) * dcoefs + noise * noise_strength + bias) * gain).
 
     x [N, I, H, W]; w [O, I, k, k] in x's dtype; styles [N, I] / dcoefs [N, O] float32 or None; noise a
     float32 plane [H', W'] or [N, 1, H', W'] (unit noise) with its scalar strength; bias [O] in x's dtype.
     Call `supported()` first.  `addend` (the output's shape and dtype) is added to the result: by the layer's own
     kernel while it stores where one does that (16-bit 1x1 layers without modulation, activation or clamp - the skip
-    of a residual block), else in place afterwards.
+    of a residual block), else in place afterwards.  `also_input` (same-size layers without addend): returns (x, y) -
+    pass that x on to the other consumer of the input, and the two gradients of x meet inside this layer's backward
+    (`_FusedConvBranch`).
     """
     spec = bias_act.activation_funcs[act]
     alpha = float(spec.def_alpha if alpha is None else alpha)
@@ -318,6 +356,11 @@ def conv_layer(x, w, f=None, up=1, down=1, padding=0, flip_weight=True, styles=N
         assert max(min(-px0, -px1), 0) == 0 and max(min(-py0, -py1), 0) == 0
         extra = _align_extra((x.shape[3] - 1) * up + k)
         cfg = ('up2', k, 2, 0, None, act, alpha, gain, clamp, (px0, px1 - extra, py0, py1), extra)
+    if also_input:
+        assert addend is None and up == 1 and down == 1
+        if _twice and torch.is_grad_enabled():
+            return x, _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
+        return _FusedConvBranch.apply(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
     if _twice and torch.is_grad_enabled():
         y = _composite(x, w, styles, dcoefs, noise, noise_strength, bias, f, cfg)
         return y if addend is None else y.add_(addend)

@@ -435,7 +435,7 @@ def _layer_styles(layer, w, weight_gain, demod_weight, kwargs):
 
 
 def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding, resample_filter, demodulate,
-                     flip_weight, act, gain, clamp, dcoefs=None):
+                     flip_weight, act, gain, clamp, dcoefs=None, also_input=False):
     """Training-path modulated convolution + bias/activation as one fused layer (same arithmetic as
     `modulated_conv2d(..., fused_modconv=False)` followed by `bias_act`, without the intermediates)."""
     out_channels, in_channels, kh, kw = weight.shape
@@ -446,7 +446,7 @@ def _modulated_layer(x, weight, styles, noise, noise_strength, bias, up, padding
         dcoefs = _demodulation(styles, weight)
     return fused_layer.conv_layer(x, _cast(weight, x.dtype), f=resample_filter, up=up, padding=padding, flip_weight=flip_weight,
                                   styles=styles, dcoefs=dcoefs, noise=noise, noise_strength=noise_strength,
-                                  bias=bias, act=act, gain=gain, clamp=clamp)
+                                  bias=bias, act=act, gain=gain, clamp=clamp, also_input=also_input)
 
 
 # ----------------------------------------------------------------------------
@@ -672,15 +672,18 @@ class ToRGBLayer(torch.nn.Module):
                             generator_requires_grad_parts)
         self.layer_idx = None
 
-    def forward(self, x, w, fused_modconv=True, noise_mode='random', **kwargs):
+    def forward(self, x, w, fused_modconv=True, noise_mode='random', also_input=False, **kwargs):
+        """`also_input`: returns (x, rgb); a caller that consumes x again (the next block) takes it from there, so that
+        the two gradients of x meet inside this layer's backward instead of in a sum of their own."""
         styles, _ = _layer_styles(self, w, self.weight_gain, None, kwargs)
         weight = memo.derived(self, 'weight', weight_sources(self), lambda: weight_to_weight(self, self.weight))
         bias = memo.derived(self, ('b', x.dtype), [self.bias], lambda: self.bias.to(x.dtype))
         if FUSE_LAYERS and not fused_modconv and fused_layer.supported(x, _cast(weight, x.dtype), 1, 1):
             return _modulated_layer(x, weight, styles, None, None, bias, 1, 0, None, False, True,
-                                    'linear', 1.0, self.conv_clamp)
-        x = modulated_conv2d(x=x, weight=weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, bias, clamp=self.conv_clamp)
+                                    'linear', 1.0, self.conv_clamp, also_input=also_input)
+        y = modulated_conv2d(x=x, weight=weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        y = bias_act.bias_act(y, bias, clamp=self.conv_clamp)
+        return (x, y) if also_input else y
 
 
 def _channels_per_resolution(resolutions, channel_base, channel_max):
@@ -763,7 +766,9 @@ class SynthesisBlock(torch.nn.Module):
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.num_torgb:
-            rgb = self.torgb(x, ws[self.num_conv], **layer_kwargs).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            # (x goes on to the next block: taken from the to-RGB layer, its two gradients meet in that layer's backward)
+            x, rgb = self.torgb(x, ws[self.num_conv], also_input=True, **layer_kwargs)
+            rgb = rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
             img = rgb if img is None else img.add_(rgb)
 
         assert x.dtype == dtype and (img is None or img.dtype == torch.float32)

@@ -348,8 +348,11 @@ typedef struct sg_conv2d_params {
     const void* w_prepared;
     /* may be NULL: a tensor of y's shape and dtype that is added to the result after the epilogue, y = epilogue(...) +
      * addend - the sum of a residual block (training/networks.py:1268-1271 `x = y.add_(x)`) formed while the skip
-     * branch is stored instead of in a pass of its own.  Only where sg_conv2d_supports_addend(p) returns 1 (16-bit 1x1
-     * layers with at least 32 input and 16 output channels and no modulation); other calls return SG_ERR_UNSUPPORTED. */
+     * branch is stored instead of in a pass of its own; or the other gradient of a tensor that feeds a to-RGB layer
+     * and the next block (training/networks.py:1041-1046), added by the to-RGB layer's data-gradient call.  Only where
+     * sg_conv2d_supports_addend(p) returns 1 (16-bit 1x1 layers with at least 32 input and 16 output channels and no
+     * modulation; 16-bit 1x1 layers with 3 input channels and a multiple of 4 output channels); other calls return
+     * SG_ERR_UNSUPPORTED.  The sum is rounded as a separate pass would: round(round(result) + addend). */
     const void* addend;
 } sg_conv2d_params;
 

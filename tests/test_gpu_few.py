@@ -101,6 +101,39 @@ def test_to_rgb_data_gradient(dtype, co, masked):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('co', [32, 64, 48, 128])
+@pytest.mark.parametrize('reduce', [False, True])
+@pytest.mark.parametrize('masked', [False, True])
+def test_to_rgb_data_gradient_with_addend(dtype, co, reduce, masked):
+    """The same call with the other gradient of the layer's input as `addend`: bit-equal to the call without it followed
+    by a sum of the two 16-bit tensors, and the reduction untouched."""
+    from ga_gan_amd import conv2d_plugin as cp
+    n, k, h, w = 3, 3, 64, 80
+    g = torch.Generator().manual_seed(co + 1000)
+    dy = torch.randn([n, k, h, w], generator=g).to(dtype).to(DEV)
+    saved = (torch.randn([n, k, h, w], generator=g) * 1.2).to(dtype).to(DEV)
+    wt = (torch.randn([co, k, 1, 1], generator=g)).to(dtype).to(DEV)
+    s = (torch.rand([n, co], generator=g) + 0.5).to(DEV)
+    rx = torch.randn([n, co, h, w], generator=g).to(dtype).to(DEV)
+    other = torch.randn([n, co, h, w], generator=g).to(dtype).to(DEV)
+    plan = cp.plan_conv(1, 1)
+    have = cp.supports_addend(dy, plan, co, reduce=reduce, mask=masked)
+    assert have == (not reduce or co in (32, 64))
+    if not have:
+        with pytest.raises(RuntimeError):
+            cp.conv2d(dy, plan.pack(wt), plan, co, out_scale=s, gain=0.5, reduce_x=rx, addend=other)
+        return
+    kw = dict(mask_y=saved, mask_alpha=1.0, mask_clamp=2.0) if masked else {}
+    kw.update(reduce_x=rx if reduce else None, out_scale=s, gain=0.5)
+    plain = cp.conv2d(dy, plan.pack(wt), plan, co, **kw)
+    fused = cp.conv2d(dy, plan.pack(wt), plan, co, addend=other, **kw)
+    if reduce:
+        (plain, r0), (fused, r1) = plain, fused
+        close(r1, r0, 1e-6, 'reduction')
+    assert torch.equal(fused, plain + other)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(3, 32, 3, 64, 64), (2, 3, 32, 64, 96), (2, 72, 3, 48, 96), (2, 4, 40, 64, 64), (3, 64, 3, 130, 136)],
                          ids=['x32_g3', 'x3_g32', 'x72_g3', 'x4_g40', 'x64_g3_big'])
 @pytest.mark.parametrize('masked', [False, True])
