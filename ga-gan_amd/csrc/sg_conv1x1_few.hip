@@ -75,6 +75,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Four per-lane values summed over the wave and added to dst[0..3] in LDS: the first two exchange steps halve the number
+// of values a lane carries (a lane keeps the pair, then the one, that its bits 5 and 4 name and hands the rest to its
+// partner), so seven exchanges do what four separate wave sums take twenty-four for.  All 64 lanes must be active.
+__device__ __forceinline__ void wave_sum4_to_lds(float r0, float r1, float r2, float r3, float* dst, int lane) {
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0;
+    float k0 = b5 ? r2 : r0, k1 = b5 ? r3 : r1;
+    k0 += __shfl_xor(b5 ? r0 : r2, 32, 64);
+    k1 += __shfl_xor(b5 ? r1 : r3, 32, 64);
+    float k = b4 ? k1 : k0;
+    k += __shfl_xor(b4 ? k0 : k1, 16, 64);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) k += __shfl_xor(k, off, 64);
+    if ((lane & 15) == 0) atomicAdd(dst + 2 * (lane >> 5) + ((lane >> 4) & 1), k);
+}
+
 struct FewArgs {
     const void* x; const void* mask_y; const void* w; void* y;
     const float* in_scale; const float* out_scale; const void* bias; const void* reduce_x; float* reduce_out;
@@ -156,11 +171,13 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_out_kernel(FewArgs g)
 // a to-RGB layer meets the other gradient of its input here instead of in a pass of its own)
 template <class T, int CI, bool MASK, int CO_R, bool ADD>
 __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) {
-    extern __shared__ float s_few[];            // [co][CI] weights x in_scale, then [co] out_scale x gain, [co] bias x gain
+    extern __shared__ float s_few[];            // [co][CI] weights x in_scale, then [co] out_scale x gain, [co] bias x gain, [CO_R] sums
     float* s_w = s_few;
     float* s_sc = s_few + g.co * CI;
     float* s_bs = s_sc + g.co;
+    float* s_red = s_bs + g.co;
     const int n = blockIdx.y, tid = threadIdx.x;
+    if (tid < CO_R) s_red[tid] = 0.f;
     for (int e = tid; e < g.co * CI; e += kFewThreads) {
         const int o = e / CI, c = e - o * CI;
         const float s = g.in_scale ? g.in_scale[(int64_t)n * CI + c] : 1.f;
@@ -177,11 +194,11 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
     const T* __restrict__ rn = (CO_R > 0) ? (const T*)g.reduce_x + (int64_t)n * g.co * plane : nullptr;
     T* __restrict__ yn = (T*)g.y + (int64_t)n * g.co * plane;
     const T* __restrict__ an = ADD ? (const T*)g.addend + (int64_t)n * g.co * plane : nullptr;
-    float red[CO_R > 0 ? CO_R : 1];
-#pragma unroll
-    for (int o = 0; o < (CO_R > 0 ? CO_R : 1); o++) red[o] = 0.f;
-
-    for (int pk = blockIdx.x * kFewThreads + tid; pk < g.packets; pk += gridDim.x * kFewThreads) {
+    // (The reduction's sums live in LDS, not in CO_R registers of every lane: with them the kernel took all 256 registers
+    // and ran one wave per SIMD - 2.8 TB/s on a kernel that only streams.)
+    for (int base = blockIdx.x * kFewThreads; base < g.packets; base += gridDim.x * kFewThreads) {   // (uniform: the sums exchange across the wave)
+        const bool valid = base + tid < g.packets;
+        const int pk = valid ? base + tid : g.packets - 1;      // a lane beyond the plane repeats the last packet and drops the result
         float xin[CI][8];
 #pragma unroll
         for (int c = 0; c < CI; c++) {
@@ -221,8 +238,8 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
                 for (int j = 0; j < 8; j++) a[j] += b[j];
                 out = pack8<T>(a);
             }
-            *reinterpret_cast<uint4*>(yn + o * plane + (int64_t)pk * 8) = out;
-            return r;
+            if (valid) *reinterpret_cast<uint4*>(yn + o * plane + (int64_t)pk * 8) = out;
+            return valid ? r : 0.f;
         };
         const uint4 zero4 = make_uint4(0, 0, 0, 0);
         if constexpr (CO_R > 0) {
@@ -242,8 +259,10 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
                         adv[((o0 >> 2) + 1) & 1][u] = ADD ? *reinterpret_cast<const uint4*>(an + (o0 + 4 + u) * plane + (int64_t)pk * 8) : zero4;
                     }
                 }
+                float r[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) red[o0 + u] += one(o0 + u, rxv[(o0 >> 2) & 1][u], adv[(o0 >> 2) & 1][u]);
+                for (int u = 0; u < 4; u++) r[u] = one(o0 + u, rxv[(o0 >> 2) & 1][u], adv[(o0 >> 2) & 1][u]);
+                wave_sum4_to_lds(r[0], r[1], r[2], r[3], s_red + o0, tid & 63);
             }
         } else if constexpr (ADD) {
             // groups of four output channels (co is a multiple of 4 with an addend, checked by the dispatcher), the next
@@ -268,12 +287,8 @@ __global__ void __launch_bounds__(kFewThreads) conv1x1_few_in_kernel(FewArgs g) 
         }
     }
     if constexpr (CO_R > 0) {
-        const int row = (blockIdx.x * (kFewThreads / 64) + (tid >> 6)) % kReduceRows;
-#pragma unroll
-        for (int o = 0; o < CO_R; o++) {
-            const float v = wave_sum(red[o]);
-            if ((tid & 63) == 0) atomicAdd(g.reduce_out + ((int64_t)n * kReduceRows + row) * CO_R + o, v);
-        }
+        __syncthreads();
+        if (tid < CO_R) atomicAdd(g.reduce_out + ((int64_t)n * kReduceRows + blockIdx.x % kReduceRows) * CO_R + tid, s_red[tid]);
     }
 }
 
@@ -439,7 +454,7 @@ int launch_few_out(const FewArgs& g, hipStream_t stream) {
 
 template <class T, int CI, bool MASK>
 int launch_few_in(const FewArgs& g, hipStream_t stream) {
-    const size_t lds = (size_t)g.co * (CI + 2) * sizeof(float);
+    const size_t lds = ((size_t)g.co * (CI + 2) + 64) * sizeof(float);
     // a lane keeps its reduction sums over several packets; without a reduction one packet per lane
     const int per_lane = g.reduce_out ? 8 : 1;
     const dim3 grid((unsigned)std::max(1, (g.packets + kFewThreads * per_lane - 1) / (kFewThreads * per_lane)), (unsigned)g.n);
