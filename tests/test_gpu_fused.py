@@ -196,3 +196,56 @@ def test_float32_layers_against_float64(case):
     assert _rel(y.detach().cpu(), c.detach()) < 5e-6
     for name, a, e in zip('x w styles dcoefs bias'.split(), leaves, exact):
         assert _rel(a.grad.cpu(), e.grad) < 5e-6, (name, _rel(a.grad.cpu(), e.grad))
+
+
+@pytest.mark.parametrize('trainable_styles', [True, False], ids=['styles', 'frozen'])
+@pytest.mark.parametrize('co_in', [32, 64, 48], ids=['c32', 'c64', 'c48'])
+def test_to_rgb_layer_that_passes_its_input_on(co_in, trainable_styles):
+    """`conv_layer(..., also_input=True)` returns (x, y); a second consumer fed from the returned x gives x the same
+    gradient - bit for bit in bfloat16 - as the plain layer whose input autograd sums over both consumers, whether the
+    layer's data-gradient kernel takes the other gradient as an addend (32 / 64 channels with the style reduction, any
+    multiple of four without) or the sum stays a step of its own."""
+    from ga_gan_amd.torch_utils.ops import fused_layer
+    n, res = 3, 64
+    results = []
+    for branch in (True, False):
+        x, w, styles, _, bias, _ = _inputs(n, co_in, 3, res, 1, torch.bfloat16, True, False, seed=co_in)
+        styles.requires_grad_(trainable_styles)
+        other = torch.randn(x.shape, device='cuda', generator=torch.Generator('cuda').manual_seed(9)).to(torch.bfloat16)
+        kw = dict(styles=styles, bias=bias, act='linear', clamp=256.0)
+        if branch:
+            x2, y = fused_layer.conv_layer(x, w, also_input=True, **kw)
+            assert x2.data_ptr() == x.data_ptr()
+        else:
+            x2, y = x, fused_layer.conv_layer(x, w, **kw)
+        dy = torch.randn(y.shape, device='cuda', generator=torch.Generator('cuda').manual_seed(5)).to(torch.bfloat16)
+        ((y * dy).sum() + (x2 * other).sum()).backward()
+        results.append((y.detach(), x.grad, w.grad, styles.grad, bias.grad))
+    for name, a, b in zip(('y', 'dx', 'dw', 'dstyles', 'dbias'), *results):
+        if b is None:
+            assert a is None, name
+        elif name in ('y', 'dx'):
+            assert torch.equal(a, b), name
+        else:
+            assert _rel(a, b) < 1e-5, name      # (float atomics: the order of the partial sums differs from run to run)
+
+
+def test_branch_layer_double_backward():
+    """The passed-through input under `create_graph` (the path-length regulariser differentiates a gradient that reached
+    the generator through both consumers of a block's output)."""
+    from ga_gan_amd.torch_utils.ops import fused_layer
+    n, ci, res = 2, 16, 32
+
+    def second_order(branch):
+        x, w, styles, _, bias, _ = _inputs(n, ci, 3, res, 1, torch.float32, True, False, seed=4)
+        kw = dict(styles=styles, bias=bias, act='linear', clamp=256.0)
+        if branch:
+            x2, y = fused_layer.conv_layer(x, w, also_input=True, **kw)
+        else:
+            x2, y = x, fused_layer.conv_layer(x, w, **kw)
+        gx, gs = torch.autograd.grad(y.square().sum() + x2.pow(3).sum(), [x, styles], create_graph=True)
+        (gx.square().sum() + gs.square().sum()).backward()
+        return x.grad, w.grad, styles.grad, bias.grad
+
+    for name, a, b in zip(('x', 'w', 'styles', 'bias'), second_order(True), second_order(False)):
+        assert _rel(a, b) < 1e-5, name
