@@ -1,5 +1,6 @@
-"""Diagnostic: cycles per phase of conv3x3_kernel's K loop (needs the stamped build tools/_variants/lib_stamps.so, see
-DESIGN.md appendix A; SG_OPS_LIBRARY must point at it).  GEO=n,ci,co,h"""
+"""Diagnostic: cycles per phase of conv3x3_kernel's K loop (needs the stamped build tools/_variants/lib_stamps.so, made by
+tools/build_variants.sh - the directory is listed in .gpurunignore, take it out of there for such a run;
+SG_OPS_LIBRARY must point at the library).  GEO=n,ci,co,h"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
