@@ -30,7 +30,6 @@ with it, and no real TensorFlow pickle can be fetched: records of real training 
 """
 import collections
 import contextlib
-import copy
 import io
 import pickle
 import re
